@@ -1,0 +1,258 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own modules.
+
+Runs only in the build container (needs /root/reference); never on the GPU box.
+It imports models/blip2/vit.py and models/blip2/Qformer.py from the reference
+checkout, fills them with the seeded synthetic weights of hawkeye_amd.weights,
+and records what the reference computes.  The HawkEye_it class itself cannot be
+instantiated offline (needs peft, Vicuna and bert-base-uncased files, SURVEY.md
+§8c), so lines hawkeye_it.py:226-269 are driven around the reference modules
+with synthetic token ids in place of the BertTokenizer.
+
+Version-drift shims (torch 2.10 / transformers 5.x vs the reference's pins),
+all in memory, none touching the reference checkout:
+  1. `timm` is absent: stub timm.models.layers.{drop_path,to_2tuple,trunc_normal_}.
+  2. transformers.modeling_utils no longer re-exports apply_chunking_to_forward,
+     find_pruneable_heads_and_indices, prune_linear_layer.
+  3. BertPreTrainedModel.init_weights -> self.apply(self._init_weights).
+  4. BertModel.get_head_mask (removed) -> [None] * n.
+
+Usage:  python oracle/make_goldens.py            (writes tests/golden/)
+"""
+import importlib.machinery
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True  # never write __pycache__ into /root/reference
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("HAWKEYE_REFERENCE", "/root/reference")
+sys.path.insert(0, REPO)
+
+from hawkeye_amd.config import FULL, SMALL, EncoderConfig  # noqa: E402
+from hawkeye_amd import weights as W  # noqa: E402
+from hawkeye_amd import posembed  # noqa: E402
+
+
+def _install_shims():
+    import transformers  # noqa: F401  (must precede the timm stub: its lazy loader probes find_spec('timm'))
+    import transformers.modeling_utils as mu
+    import transformers.pytorch_utils as pu
+
+    def drop_path(x, drop_prob: float = 0.0, training: bool = False):
+        if drop_prob == 0.0 or not training:
+            return x
+        raise RuntimeError("goldens are generated in eval mode")
+
+    def to_2tuple(x):
+        return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+
+    for name in ("timm", "timm.models", "timm.models.layers"):
+        m = types.ModuleType(name)
+        m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+        m.__path__ = []
+        sys.modules[name] = m
+    lay = sys.modules["timm.models.layers"]
+    lay.drop_path = drop_path
+    lay.to_2tuple = to_2tuple
+    lay.trunc_normal_ = nn.init.trunc_normal_
+    sys.modules["timm"].models = sys.modules["timm.models"]
+    sys.modules["timm.models"].layers = lay
+
+    mu.apply_chunking_to_forward = pu.apply_chunking_to_forward
+    mu.prune_linear_layer = pu.prune_linear_layer
+    if not hasattr(mu, "find_pruneable_heads_and_indices"):
+        def find_pruneable_heads_and_indices(*a, **k):
+            raise NotImplementedError
+        mu.find_pruneable_heads_and_indices = find_pruneable_heads_and_indices
+
+
+def _import_reference():
+    _install_shims()
+    sys.path.insert(0, REF)
+    import models.blip2.vit as ref_vit
+    import models.blip2.Qformer as ref_qf
+    ref_qf.BertPreTrainedModel.init_weights = lambda self: self.apply(self._init_weights)
+    ref_qf.BertModel.get_head_mask = lambda self, hm, n, *a, **k: [None] * n
+    return ref_vit, ref_qf
+
+
+class _Cfg(dict):
+    """EasyDict stand-in (attribute + .get access) for build_vit (vit.py:408-422)."""
+    __getattr__ = dict.__getitem__
+
+
+def build_reference(cfg: EncoderConfig, sd, ref_vit, ref_qf):
+    """Mirror of Blip2Base.init_vision_encoder_umt / init_Qformer (blip2.py:47-87)
+    and HawkEye_it.__init__ lines 57-80,183-185 for the hot-path modules only."""
+    vcfg = _Cfg(vision_encoder=_Cfg(
+        img_size=cfg.img_size, patch_size=cfg.patch_size, encoder_embed_dim=cfg.encoder_embed_dim,
+        encoder_depth=cfg.encoder_depth, encoder_num_heads=cfg.encoder_num_heads, drop_path_rate=0.0,
+        num_frames=cfg.num_frames, tubelet_size=1, use_checkpoint=False, checkpoint_num=0,
+        return_index=cfg.return_index, pretrained="", vit_add_ln=True))
+    vision_encoder = ref_vit.build_vit(vcfg)
+    vision_layernorm = nn.LayerNorm(cfg.encoder_embed_dim, eps=1e-12)
+
+    bc = ref_qf.BertConfig(
+        vocab_size=cfg.qf_vocab - 1, hidden_size=cfg.qf_hidden, num_hidden_layers=cfg.qf_layers,
+        num_attention_heads=cfg.qf_heads, intermediate_size=cfg.qf_intermediate,
+        max_position_embeddings=cfg.qf_max_pos)
+    bc.num_frame_tokens = 0
+    bc.encoder_width = cfg.encoder_embed_dim
+    bc.add_cross_attention = True
+    bc.cross_attention_freq = cfg.cross_attention_freq
+    bc.query_length = cfg.num_query_token
+    bc.hidden_dropout_prob = 0.1
+    bc.attention_probs_dropout_prob = 0.1
+    bc.drop_path_list = [x.item() for x in torch.linspace(0, 0.2, cfg.qf_layers)]
+    qformer = ref_qf.BertLMHeadModel(config=bc)
+    qformer.cls = None
+    # resize_token_embeddings(len(tokenizer)) (hawkeye_it.py:72): +1 row for [DEC]
+    qformer.bert.embeddings.word_embeddings = nn.Embedding(cfg.qf_vocab, cfg.qf_hidden, padding_idx=0)
+    llama_proj = nn.Linear(cfg.qf_hidden, cfg.llama_hidden)
+
+    class Holder(nn.Module):
+        pass
+
+    m = Holder()
+    m.query_tokens = nn.Parameter(torch.zeros(1, cfg.num_query_token, cfg.qf_hidden))
+    m.vision_encoder = vision_encoder
+    m.vision_layernorm = vision_layernorm
+    m.qformer = qformer
+    m.extra_query_tokens = nn.Parameter(torch.zeros(1, cfg.extra_num_query_token, cfg.qf_hidden))
+    m.llama_proj = llama_proj
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not missing, missing
+    assert not unexpected, unexpected
+    return m.eval()
+
+
+@torch.no_grad()
+def reference_encode_img(m, image, input_ids, text_mask, stages=None):
+    """hawkeye_it.py:226-269 around the reference modules (CPU => no autocast)."""
+    hooks = []
+    if stages is not None:
+        enc = m.vision_encoder.encoder
+        hooks.append(enc.patch_embed.register_forward_hook(lambda mod, i, o: stages.__setitem__("patch_embed", o)))
+        last = len(enc.blocks) - 1
+        hooks.append(enc.blocks[0].register_forward_hook(lambda mod, i, o: stages.__setitem__("vit_block_0", o)))
+        hooks.append(enc.blocks[last].register_forward_hook(
+            lambda mod, i, o: stages.__setitem__(f"vit_block_{last}", o)))
+        hooks.append(m.qformer.bert.embeddings.register_forward_hook(
+            lambda mod, i, o: stages.__setitem__("qf_embeddings", o)))
+        for li, layer in enumerate(m.qformer.bert.encoder.layer):
+            hooks.append(layer.register_forward_hook(
+                lambda mod, i, o, li=li: stages.__setitem__(f"qf_layer_{li}", o[0])))
+    T = image.shape[1]
+    use_image = True if T == 1 else False
+    image = image.permute(0, 2, 1, 3, 4)
+    image_embeds = m.vision_encoder(image, use_image)
+    B, T, L, C = image_embeds.shape
+    image_embeds = image_embeds.reshape(B, -1, C)
+    image_embeds = m.vision_layernorm(image_embeds)
+    if stages is not None:
+        stages["vision_layernorm"] = image_embeds
+    image_atts = torch.ones(image_embeds.size()[:-1], dtype=torch.long)
+    query_tokens = torch.cat([m.query_tokens, m.extra_query_tokens], dim=1)
+    query_tokens = query_tokens.expand(image_embeds.shape[0], -1, -1)
+    query_atts = torch.ones(query_tokens.size()[:-1], dtype=torch.long)
+    qformer_atts = torch.cat([query_atts, text_mask], dim=1)
+    query_output = m.qformer.bert(
+        input_ids, attention_mask=qformer_atts, query_embeds=query_tokens,
+        encoder_hidden_states=image_embeds, encoder_attention_mask=image_atts, return_dict=True)
+    out = m.llama_proj(query_output.last_hidden_state[:, :query_tokens.size(1), :])
+    for h in hooks:
+        h.remove()
+    return out, use_image
+
+
+def digest(t: torch.Tensor):
+    """Size-independent summary + a fixed slice of a stage tensor [B, rows, cols]."""
+    t = t.detach().float()
+    flat = t.reshape(-1, t.shape[-1])
+    r = min(8, flat.shape[0])
+    c = min(16, flat.shape[1])
+    rows = np.linspace(0, flat.shape[0] - 1, r).astype(np.int64)
+    cols = np.linspace(0, flat.shape[1] - 1, c).astype(np.int64)
+    sl = flat[torch.from_numpy(rows)][:, torch.from_numpy(cols)].numpy()
+    return dict(shape=np.array(t.shape, dtype=np.int64), mean=np.float64(t.double().mean().item()),
+                std=np.float64(t.double().std().item()), l2=np.float64(t.double().norm().item()),
+                rows=rows, cols=cols, slice=sl)
+
+
+def run_case(name, cfg: EncoderConfig, B, T, Lt, seed, ragged, full_tensors, ref_vit, ref_qf, outdir):
+    sd = W.make_state_dict(cfg, seed)
+    m = build_reference(cfg, sd, ref_vit, ref_qf)
+    image = W.make_clip(B, T, cfg.img_size, seed)
+    ids, mask = W.make_instruction_ids(B, Lt, cfg.qf_vocab, seed, ragged)
+    enc = m.vision_encoder.encoder
+    L = cfg.patches_per_frame
+    if T == 1:
+        table = posembed.image_pos_embed(L, cfg.encoder_embed_dim)
+        enc.img_pos_embed = table
+    else:
+        # the caller-assigned table path (demo.ipynb cell 6): a table for this T
+        table = posembed.video_pos_embed(T, L, cfg.encoder_embed_dim, cfg.ckpt_num_frame)
+        enc.pos_embed = table
+    stages = {}
+    out, use_image = reference_encode_img(m, image, ids, mask, stages)
+    rec = dict(B=np.int64(B), T=np.int64(T), Lt=np.int64(Lt), seed=np.int64(seed), ragged=np.int64(ragged),
+               use_image=np.int64(use_image), input_ids=ids.numpy(), text_mask=mask.numpy())
+    if full_tensors:
+        rec["out"] = out.numpy()
+        for k, v in stages.items():
+            rec["stage." + k] = v.numpy()
+    else:
+        rec["out"] = out.numpy().astype(np.float32)
+        for k, v in stages.items():
+            for dk, dv in digest(v).items():
+                rec[f"digest.{k}.{dk}"] = dv
+    path = os.path.join(outdir, name + ".npz")
+    np.savez_compressed(path, **rec)
+    print(f"wrote {path}: out{tuple(out.shape)} mean={out.mean():.5f} std={out.std():.5f}")
+
+
+def pos_embed_goldens(ref_vit, outdir):
+    """get_sinusoid_encoding_table (vit.py:163-194) at the shipped sizes."""
+    rec = {}
+    for T in (1, 4, 8, 12, 16):
+        if T == 1:
+            t = ref_vit.get_sinusoid_encoding_table(196, 1024)
+        else:
+            t = ref_vit.get_sinusoid_encoding_table(196 * T, 1024, ckpt_num_frame=4, cur_frame=T)
+        t = t.reshape(-1, 1024)
+        rows = np.linspace(0, t.shape[0] - 1, 64).astype(np.int64)
+        rec[f"T{T}.rows"] = rows
+        rec[f"T{T}.vals"] = t[torch.from_numpy(rows)].numpy()
+        rec[f"T{T}.l2"] = np.float64(t.double().norm().item())
+    np.savez_compressed(os.path.join(outdir, "pos_embed.npz"), **rec)
+    print("wrote pos_embed.npz")
+
+
+def main():
+    torch.manual_seed(0)
+    outdir = os.path.join(REPO, "tests", "golden")
+    os.makedirs(outdir, exist_ok=True)
+    ref_vit, ref_qf = _import_reference()
+    pos_embed_goldens(ref_vit, outdir)
+    # reduced shape: every stage tensor in full
+    run_case("small_video", SMALL, B=2, T=2, Lt=6, seed=3, ragged=True, full_tensors=True,
+             ref_vit=ref_vit, ref_qf=ref_qf, outdir=outdir)
+    run_case("small_image", SMALL, B=2, T=1, Lt=5, seed=4, ragged=False, full_tensors=True,
+             ref_vit=ref_vit, ref_qf=ref_qf, outdir=outdir)
+    # full shape: final output in full + per-stage digests
+    run_case("full_T8_B1", FULL, B=1, T=8, Lt=12, seed=0, ragged=False, full_tensors=False,
+             ref_vit=ref_vit, ref_qf=ref_qf, outdir=outdir)
+    run_case("full_T1_B2", FULL, B=2, T=1, Lt=9, seed=5, ragged=True, full_tensors=False,
+             ref_vit=ref_vit, ref_qf=ref_qf, outdir=outdir)
+    if os.environ.get("HAWKEYE_GOLDEN_T16", "1") == "1":
+        run_case("full_T16_B1", FULL, B=1, T=16, Lt=32, seed=1, ragged=False, full_tensors=False,
+                 ref_vit=ref_vit, ref_qf=ref_qf, outdir=outdir)
+
+
+if __name__ == "__main__":
+    main()
