@@ -1,0 +1,308 @@
+// Fused flash-style attention forward for gfx950, head size 64, bf16 in/out, fp32 online softmax.
+//
+// One workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 query rows and
+// walks the keys in 64-key tiles staged through LDS (double-buffered, register-staged loads issued
+// one tile ahead).  Everything is computed TRANSPOSED with v_mfma_f32_32x32x16_bf16 so that the
+// query row lives on the lane:
+//     S^T[key][q] = K . Q^T          (A operand = K tile rows from LDS, B operand = Q rows in registers)
+//     O^T[d][q]  += V^T . P^T        (A operand = V^T via ds_read_b64_tr_b16, B operand = exp2(S^T - m))
+// The S^T accumulator of a lane is already the B-operand fragment of the second product (the
+// accumulator-as-operand property of the 32x32 shape), so P never crosses lanes or LDS; the only
+// cross-lane step per tile is one v_permlane32_swap for the row maximum.  The k order inside one
+// 16-key MFMA step is the accumulator's (key = 16s + 8(j>>2) + 4h + (j&3) for element j of lane
+// half h), and the V^T fragments are gathered in that same order.
+//
+// Q must arrive pre-multiplied by softmax_scale * log2(e) (folded into the producing GEMM), so the
+// kernel works in the exp2 domain with no per-score multiply.
+//
+// LDS images (128-byte rows = one key's 64 head dims), 16-byte chunk c of key row r stored at
+//     K: chunk c ^ ((r >> 1) & 7)        -> conflict-free ds_read_b128 of 32 rows x one chunk
+//     V: chunk c ^ (((r >> 1) & 1) << 2) -> conflict-free ds_read_b64_tr_b16 of 4 keys x 32 dims
+#include "hk_common.h"
+
+namespace {
+
+struct AttnParams {
+    const __bf16* Q;
+    const __bf16* K;
+    const __bf16* V;
+    __bf16* O;
+    const float* key_bias;
+    int B, H, Nq, Nk;
+    int64_t ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso;
+    int nqb;
+};
+
+constexpr int QB = 128;   // query rows per workgroup
+constexpr int KT = 64;    // keys per tile
+constexpr float NEG_BIG = -1.0e30f;
+
+// v_permlane32_swap exchanges lanes 32-63 of its first operand with lanes 0-31 of its second:
+// called on two copies of x, one result holds (own, partner) and the other (partner, own).
+// Inline asm, not __builtin_amdgcn_permlane32_swap: ROCm 7.2's clang returns the first result in
+// both elements of the builtin's vector (fmaxf(r[0], r[1]) folds to r[0]).  The s_nop covers the
+// VALU-write -> v_permlane read hazard (2 wait states), which hipcc does not pad inside asm.
+__device__ __forceinline__ void half_swap(float x, float& a, float& b) {
+    a = x;
+    b = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float half_swap_max(float x) {
+    float a, b;
+    half_swap(x, a, b);
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ float half_swap_sum(float x) {
+    float a, b;
+    half_swap(x, a, b);
+    return a + b;
+}
+
+template <bool HAS_BIAS>
+__global__ __launch_bounds__(256) void hk_attn_kernel(const AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KT * 128];  // [stage][K|V][64 keys][128 B]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int r = lane & 31;   // query row within the wave's block (MFMA column)
+    const int h = lane >> 5;   // lane half
+
+    // XCD-aware remap: the query blocks of one (batch, head) run on one XCD so K/V stay in its L2.
+    const int nwg = gridDim.x;
+    int lid;
+    {
+        const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, rem = nwg & 7;
+        lid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (orig >> 3);
+    }
+    const int bh = lid / p.nqb;
+    const int qb = lid - bh * p.nqb;
+    const int b = bh / p.H;
+    const int head = bh - b * p.H;
+    const int q0 = qb * QB + wave * 32;
+
+    // ---- Q fragments: B operand, lane (r, h) holds Q[q0 + r][16 ks + 8 h .. +8] ----
+    bf16x8 qf[4];
+    {
+        const int qrow = min(q0 + r, p.Nq - 1);
+        const __bf16* qp = p.Q + (int64_t)b * p.bsq + (int64_t)qrow * p.ldq + head * 64 + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+    }
+
+    // ---- K/V tile loader: 256 threads x 16 B x 2 passes per operand ----
+    const __bf16* kbase = p.K + (int64_t)b * p.bsk + head * 64 + (tid & 7) * 8;
+    const __bf16* vbase = p.V + (int64_t)b * p.bsv + head * 64 + (tid & 7) * 8;
+    const int lkey = tid >> 3;  // 0..31 (+32 on the second pass)
+    int kst[2], vst[2];         // LDS byte offsets of this thread's two chunks
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int key = i * 32 + lkey, c = tid & 7;
+        kst[i] = key * 128 + ((c ^ ((key >> 1) & 7)) << 4);
+        vst[i] = key * 128 + ((c ^ (((key >> 1) & 1) << 2)) << 4);
+    }
+    bf16x8 kr[2], vr[2];
+    auto gload = [&](int tile) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int key = min(tile * KT + i * 32 + lkey, p.Nk - 1);
+            kr[i] = *reinterpret_cast<const bf16x8*>(kbase + (int64_t)key * p.ldk);
+            vr[i] = *reinterpret_cast<const bf16x8*>(vbase + (int64_t)key * p.ldv);
+        }
+    };
+    auto lstore = [&](int stage) {
+        char* ks = smem + stage * (2 * KT * 128);
+        char* vs = ks + KT * 128;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<bf16x8*>(ks + kst[i]) = kr[i];
+            *reinterpret_cast<bf16x8*>(vs + vst[i]) = vr[i];
+        }
+    };
+
+    // ---- per-lane LDS read offsets ----
+    // K fragment (kt, ks): row 32 kt + r, logical chunk 2 ks + h
+    const int ksw = (r >> 1) & 7;
+    int koff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = r * 128 + (((2 * ks + h) ^ ksw) << 4);
+    // V^T fragment (s, dt, half-read u): keys 16 s + 8 u + 4 h + ((lane & 15) >> 2),
+    // dims 32 dt + 16 ((lane >> 4) & 1) + 4 (lane & 3)
+    const int vq = (lane & 15) >> 2;
+    const int vsb = (vq >> 1) & 1;  // swizzle bit of that key row
+    int voff[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        const int c = 4 * dt + 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);
+        voff[dt] = (4 * h + vq) * 128 + ((c ^ (vsb << 2)) << 4) + 8 * (lane & 1);
+    }
+
+    f32x16 ot[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ot[dt][i] = 0.f;
+    float m_run = NEG_BIG, l_run = 0.f;
+
+    const int NT = (p.Nk + KT - 1) / KT;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    for (int t = 0; t < NT; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < NT) gload(t + 1);
+        const char* ks = smem + cur * (2 * KT * 128);
+        const char* vs = ks + KT * 128;
+
+        // ---- S^T = K . Q^T ----
+        f32x16 st[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) st[kt][i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + kt * 32 * 128 + koff[s]);
+                st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[kt], 0, 0, 0);
+            }
+        }
+        // register i of st[kt] <-> key t*64 + 32 kt + (i & 3) + 8 (i >> 2) + 4 h
+        if (HAS_BIAS) {
+            const float* kb = p.key_bias + (int64_t)b * p.Nk;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = t * KT + 32 * kt + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (key < p.Nk) st[kt][i] += kb[key] * HK_LOG2E;
+                }
+        }
+        if ((t + 1) * KT > p.Nk) {  // ragged last tile: keys >= Nk do not exist
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = t * KT + 32 * kt + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (key >= p.Nk) st[kt][i] = NEG_BIG;
+                }
+        }
+
+        // ---- online softmax (exp2 domain), row = lane column, both lane halves share a row ----
+        float mx = st[0][0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, st[0][i]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, st[1][i]);
+        mx = half_swap_max(mx);
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float rs = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float e = __builtin_amdgcn_exp2f(st[kt][i] - m_new);
+                st[kt][i] = e;
+                rs += e;
+            }
+        l_run = l_run * alpha + rs;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ot[dt][i] *= alpha;
+
+        // ---- P^T fragments straight from the accumulator registers ----
+        bf16x8 pf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            u32x4 w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                w[j] = pack_bf16x2(st[s >> 1][8 * (s & 1) + 2 * j], st[s >> 1][8 * (s & 1) + 2 * j + 1]);
+            pf[s] = __builtin_bit_cast(bf16x8, w);
+        }
+
+        // ---- O^T += V^T . P^T ----
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const char* vp = vs + s * 16 * 128 + voff[dt];
+                const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (__attribute__((address_space(3))) bf16x4*)(vp));
+                const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (__attribute__((address_space(3))) bf16x4*)(vp + 8 * 128));
+                bf16x8 vf;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    vf[j] = v0[j];
+                    vf[j + 4] = v1[j];
+                }
+                ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], ot[dt], 0, 0, 0);
+            }
+        }
+
+        if (t + 1 < NT) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- normalise and store: lane (r, h) holds O[q0 + r][32 dt + 8 g + 4 h .. +4] ----
+    const float l_tot = half_swap_sum(l_run);
+    const float inv = 1.0f / l_tot;
+    const int qrow = q0 + r;
+    if (qrow < p.Nq) {
+        __bf16* op = p.O + (int64_t)b * p.bso + (int64_t)qrow * p.ldo + head * 64 + 4 * h;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 o;
+                o[0] = pack_bf16x2(ot[dt][4 * g] * inv, ot[dt][4 * g + 1] * inv);
+                o[1] = pack_bf16x2(ot[dt][4 * g + 2] * inv, ot[dt][4 * g + 3] * inv);
+                *reinterpret_cast<u32x2*>(op + 32 * dt + 8 * g) = o;
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int hk_flash_attn_bf16(const hk_attn_desc* d, void* stream) {
+    HK_REQUIRE(d != nullptr, "hk_flash_attn_bf16: null descriptor");
+    HK_REQUIRE(d->Q && d->K && d->V && d->O, "hk_flash_attn_bf16: null operand pointer");
+    HK_REQUIRE(d->B > 0 && d->H > 0 && d->Nq > 0 && d->Nk > 0, "hk_flash_attn_bf16: empty problem B=%d H=%d Nq=%d Nk=%d",
+               d->B, d->H, d->Nq, d->Nk);
+    HK_REQUIRE(((uintptr_t)d->Q | (uintptr_t)d->K | (uintptr_t)d->V | (uintptr_t)d->O) % 16 == 0,
+               "hk_flash_attn_bf16: operands must be 16-byte aligned");
+    HK_REQUIRE((d->ldq | d->ldk | d->ldv | d->bsq | d->bsk | d->bsv) % 8 == 0 && (d->ldo | d->bso) % 4 == 0,
+               "hk_flash_attn_bf16: strides must keep 16-byte (Q,K,V) / 8-byte (O) alignment");
+    AttnParams p;
+    p.Q = reinterpret_cast<const __bf16*>(d->Q);
+    p.K = reinterpret_cast<const __bf16*>(d->K);
+    p.V = reinterpret_cast<const __bf16*>(d->V);
+    p.O = reinterpret_cast<__bf16*>(d->O);
+    p.key_bias = d->key_bias;
+    p.B = d->B;
+    p.H = d->H;
+    p.Nq = d->Nq;
+    p.Nk = d->Nk;
+    p.ldq = d->ldq;
+    p.ldk = d->ldk;
+    p.ldv = d->ldv;
+    p.ldo = d->ldo;
+    p.bsq = d->bsq;
+    p.bsk = d->bsk;
+    p.bsv = d->bsv;
+    p.bso = d->bso;
+    p.nqb = (d->Nq + QB - 1) / QB;
+    const long nwg = (long)p.nqb * d->H * d->B;
+    HK_REQUIRE(nwg < (1L << 31), "hk_flash_attn_bf16: grid too large");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (d->key_bias)
+        hipLaunchKernelGGL(hk_attn_kernel<true>, dim3((unsigned)nwg), dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL(hk_attn_kernel<false>, dim3((unsigned)nwg), dim3(256), 0, s, p);
+    HK_CHECK_LAUNCH("hk_flash_attn_bf16");
+    return HK_OK;
+}

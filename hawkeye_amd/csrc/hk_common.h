@@ -1,0 +1,51 @@
+// Shared device/host helpers for the gfx950 kernels (wave64, MFMA, LDS-DMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/hawkeye_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define HK_LOG2E 1.4426950408889634f
+
+// fp32 -> bf16 with round-to-nearest-even; hipcc lowers the cast to v_cvt_pk_bf16_f32 on gfx950.
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    bf16x2 v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float bf16_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+
+// LDS-DMA: 16 bytes per lane, destination = wave-uniform LDS base + lane * 16.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+void hk_set_error(const char* fmt, ...);
+
+#define HK_REQUIRE(cond, ...)            \
+    do {                                 \
+        if (!(cond)) {                   \
+            hk_set_error(__VA_ARGS__);   \
+            return HK_EINVAL;            \
+        }                                \
+    } while (0)
+
+#define HK_CHECK_LAUNCH(name)                                               \
+    do {                                                                    \
+        hipError_t e_ = hipGetLastError();                                  \
+        if (e_ != hipSuccess) {                                             \
+            hk_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+            return HK_ELAUNCH;                                              \
+        }                                                                   \
+    } while (0)

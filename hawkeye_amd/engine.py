@@ -1,0 +1,330 @@
+"""Execution engine of the MI355X encode_img path.
+
+`HipEncoderEngine` owns (a) the packed device weights -- bf16 GEMM operands in
+nn.Linear layout, fp32 biases / LayerNorm terms, the fused QKV and 6-layer
+cross-K/V matrices -- and (b) one *plan* per input shape (B, T, Lt): a persistent
+workspace in HBM plus the flat list of C-ABI calls (descriptors prebuilt) that
+`HawkEye_it.encode_img` (models/hawkeye_it.py:219-270) lowers to.  Running a plan
+is a loop of ctypes calls on the current HIP stream: no allocation, no host
+synchronisation, no PyTorch arithmetic.
+
+Data layout in HBM (row-major, M = B*N image tokens, N = T*L):
+    x      fp32 [M, D]      residual stream of the ViT (updated in place by the proj / fc2 epilogues)
+    xn     bf16 [M, D]      LayerNorm output = GEMM operand
+    qkv    bf16 [M, 3D]     columns [q | k | v], head h at h*64 inside each third (vit.py:88)
+    att    bf16 [M, D]      attention output, already in the [B,N,H*64] layout proj consumes (vit.py:97)
+    hid    bf16 [M, 4D]     GELU(fc1)
+    kvc    bf16 [M, 2*d*n_cross]  cross-attention K|V of all cross layers from ONE GEMM
+    Q-Former hidden states: fp32 + bf16 copies [B, S, d], S = n_query + Lt
+"""
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import lib as L
+from . import ops
+from .config import EncoderConfig
+
+LOG2E = 1.4426950408889634
+
+
+class _Plan:
+    def __init__(self):
+        self.ws: Dict[str, torch.Tensor] = {}
+        self.steps: List[Tuple] = []       # (fn, args) ; stream appended at run time
+        self.keep: List = []               # descriptors / ctypes objects kept alive
+        self.patch_desc: Optional[L.HkGemmDesc] = None
+
+    def buf(self, name, shape, dtype, device):
+        t = torch.empty(shape, dtype=dtype, device=device)
+        self.ws[name] = t
+        return t
+
+
+class HipEncoderEngine:
+    def __init__(self, cfg: EncoderConfig, device="cuda"):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("HipEncoderEngine runs on an MI355X only (device must be cuda:N)")
+        self.lib = L.load()
+        if cfg.encoder_embed_dim % (64 * cfg.encoder_num_heads) != 0 or \
+                cfg.encoder_embed_dim // cfg.encoder_num_heads != 64 or cfg.qf_hidden // cfg.qf_heads != 64:
+            raise RuntimeError("the HIP attention kernel is specialised for head size 64")
+        self.w: Dict[str, torch.Tensor] = {}
+        self.plans: Dict[Tuple[int, int, int], _Plan] = {}
+        self.n_cross = len([i for i in range(cfg.qf_layers) if i % cfg.cross_attention_freq == 0])
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        """Pack a reference-keyed fp32 state dict into device operands."""
+        cfg, dev = self.cfg, self.device
+        w: Dict[str, torch.Tensor] = {}
+
+        def f32(key):
+            return sd[key].detach().to(device=dev, dtype=torch.float32).contiguous()
+
+        def bf(t):
+            return ops.cast_bf16(t.to(device=dev, dtype=torch.float32).contiguous())
+
+        with torch.cuda.device(dev):
+            D = cfg.encoder_embed_dim
+            p = "vision_encoder.encoder."
+            w["patch.w"] = bf(sd[p + "patch_embed.proj.weight"].detach().reshape(D, -1))
+            w["patch.b"] = f32(p + "patch_embed.proj.bias")
+            for i in range(cfg.run_depth):
+                b = f"{p}blocks.{i}."
+                o = f"vit.{i}."
+                w[o + "ln1.g"], w[o + "ln1.b"] = f32(b + "norm1.weight"), f32(b + "norm1.bias")
+                w[o + "qkv.w"] = bf(sd[b + "attn.qkv.weight"].detach())
+                qb, vb = f32(b + "attn.q_bias"), f32(b + "attn.v_bias")
+                w[o + "qkv.b"] = torch.cat((qb, torch.zeros_like(vb), vb)).contiguous()   # vit.py:85
+                w[o + "proj.w"], w[o + "proj.b"] = bf(sd[b + "attn.proj.weight"].detach()), f32(b + "attn.proj.bias")
+                w[o + "ln2.g"], w[o + "ln2.b"] = f32(b + "norm2.weight"), f32(b + "norm2.bias")
+                w[o + "fc1.w"], w[o + "fc1.b"] = bf(sd[b + "mlp.fc1.weight"].detach()), f32(b + "mlp.fc1.bias")
+                w[o + "fc2.w"], w[o + "fc2.b"] = bf(sd[b + "mlp.fc2.weight"].detach()), f32(b + "mlp.fc2.bias")
+            w["vln.g"], w["vln.b"] = f32("vision_layernorm.weight"), f32("vision_layernorm.bias")
+
+            q = "qformer.bert."
+            w["emb.word"] = f32(q + "embeddings.word_embeddings.weight")
+            w["emb.pos"] = f32(q + "embeddings.position_embeddings.weight")
+            w["emb.ln.g"], w["emb.ln.b"] = f32(q + "embeddings.LayerNorm.weight"), f32(q + "embeddings.LayerNorm.bias")
+            qt = sd["query_tokens"].detach()
+            if cfg.extra_num_query_token > 0:
+                qt = torch.cat([qt, sd["extra_query_tokens"].detach().to(qt.device)], dim=1)   # hawkeye_it.py:238
+            w["query"] = qt.reshape(-1, cfg.qf_hidden).to(device=dev, dtype=torch.float32).contiguous()
+            kv_w, kv_b = [], []
+            for i in range(cfg.qf_layers):
+                l = f"{q}encoder.layer.{i}."
+                o = f"qf.{i}."
+                s = l + "attention.self."
+                w[o + "qkv.w"] = bf(torch.cat([sd[s + n + ".weight"].detach() for n in ("query", "key", "value")]))
+                w[o + "qkv.b"] = torch.cat([f32(s + n + ".bias") for n in ("query", "key", "value")]).contiguous()
+                w[o + "ao.w"], w[o + "ao.b"] = bf(sd[l + "attention.output.dense.weight"].detach()), f32(l + "attention.output.dense.bias")
+                w[o + "ao.g"], w[o + "ao.bt"] = f32(l + "attention.output.LayerNorm.weight"), f32(l + "attention.output.LayerNorm.bias")
+                if i % cfg.cross_attention_freq == 0:
+                    c = l + "crossattention."
+                    w[o + "cq.w"], w[o + "cq.b"] = bf(sd[c + "self.query.weight"].detach()), f32(c + "self.query.bias")
+                    kv_w += [sd[c + "self.key.weight"].detach(), sd[c + "self.value.weight"].detach()]
+                    kv_b += [f32(c + "self.key.bias"), f32(c + "self.value.bias")]
+                    w[o + "co.w"], w[o + "co.b"] = bf(sd[c + "output.dense.weight"].detach()), f32(c + "output.dense.bias")
+                    w[o + "co.g"], w[o + "co.bt"] = f32(c + "output.LayerNorm.weight"), f32(c + "output.LayerNorm.bias")
+                for tag, a, bb in (("t", "intermediate.", "output."), ("q", "intermediate_query.", "output_query.")):
+                    w[o + tag + "i.w"], w[o + tag + "i.b"] = bf(sd[l + a + "dense.weight"].detach()), f32(l + a + "dense.bias")
+                    w[o + tag + "o.w"], w[o + tag + "o.b"] = bf(sd[l + bb + "dense.weight"].detach()), f32(l + bb + "dense.bias")
+                    w[o + tag + "o.g"], w[o + tag + "o.bt"] = f32(l + bb + "LayerNorm.weight"), f32(l + bb + "LayerNorm.bias")
+            # all cross layers read the same image_embeds (Qformer.py:198-201): one [2*d*n_cross, D] weight
+            w["ckv.w"] = bf(torch.cat([t.to("cpu") for t in kv_w]))
+            w["ckv.b"] = torch.cat(kv_b).contiguous()
+            w["proj.w"], w["proj.b"] = bf(sd["llama_proj.weight"].detach()), f32("llama_proj.bias")
+        self.w = w
+        return self
+
+    # ------------------------------------------------------------------ plan
+    def _gemm(self, plan, A, W, Cout, M, N, K, **kw):
+        d = ops.gemm_desc(A, W.data_ptr(), Cout, M, N, K, **kw)
+        plan.keep.append(d)
+        plan.steps.append((self.lib.hk_gemm_bf16, (C.byref(d),), "hk_gemm_bf16"))
+        return d
+
+    def _attn(self, plan, *a, **kw):
+        d = ops.attn_desc(*a, **kw)
+        plan.keep.append(d)
+        plan.steps.append((self.lib.hk_flash_attn_bf16, (C.byref(d),), "hk_flash_attn_bf16"))
+
+    def _ln(self, plan, x, in_f32, gamma, beta, ob, of, rows, D, eps, out_rows=None):
+        orow = None
+        if out_rows is not None:
+            r = L.HkRows(*out_rows)
+            plan.keep.append(r)
+            orow = C.byref(r)
+        plan.steps.append((self.lib.hk_layernorm,
+                           (x, L.HK_DT_F32 if in_f32 else L.HK_DT_BF16, None, gamma.data_ptr(), beta.data_ptr(),
+                            ob, of, orow, rows, D, eps), "hk_layernorm"))
+
+    def _build_plan(self, B: int, T: int, Lt: int) -> _Plan:
+        cfg, dev, w = self.cfg, self.device, self.w
+        plan = _Plan()
+        D, Hv = cfg.encoder_embed_dim, cfg.encoder_num_heads
+        Lp = cfg.patches_per_frame
+        N = T * Lp
+        M = B * N
+        Kp = cfg.patch_k
+        d, Hq, inter = cfg.qf_hidden, cfg.qf_heads, cfg.qf_intermediate
+        nq = cfg.n_query
+        S = nq + Lt
+        KVW = 2 * d * self.n_cross
+        bf16, f32 = torch.bfloat16, torch.float32
+        with torch.cuda.device(dev):
+            pa = plan.buf("patches", (M, Kp), bf16, dev)
+            x = plan.buf("x", (M, D), f32, dev)
+            xn = plan.buf("xn", (M, D), bf16, dev)
+            qkv = plan.buf("qkv", (M, 3 * D), bf16, dev)
+            att = plan.buf("att", (M, D), bf16, dev)
+            hid = plan.buf("hid", (M, D * cfg.mlp_ratio), bf16, dev)
+            kvc = plan.buf("kvc", (M, KVW), bf16, dev)
+            ids = plan.buf("ids", (B, max(Lt, 1)), torch.int64, dev)
+            kbias = plan.buf("kbias", (B, S), f32, dev)
+            hf = plan.buf("hf", (B * S, d), f32, dev)
+            hb = plan.buf("hb", (B * S, d), bf16, dev)
+            qqkv = plan.buf("qqkv", (B * S, 3 * d), bf16, dev)
+            ctx = plan.buf("ctx", (B * S, d), bf16, dev)
+            tf = plan.buf("tf", (B * S, d), f32, dev)
+            af = plan.buf("af", (B * S, d), f32, dev)
+            ab = plan.buf("ab", (B * S, d), bf16, dev)
+            cq = plan.buf("cq", (B * nq, d), bf16, dev)
+            cctx = plan.buf("cctx", (B * nq, d), bf16, dev)
+            cf = plan.buf("cf", (B * nq, d), f32, dev)
+            cb = plan.buf("cb", (B * nq, d), bf16, dev)
+            fh = plan.buf("fh", (B * max(nq, Lt), inter), bf16, dev)
+            out = plan.buf("out", (B * nq, cfg.llama_hidden), f32, dev)
+
+        P = lambda t: t.data_ptr()  # noqa: E731
+        plain = lambda ld: (ld, 0, 0)  # noqa: E731
+
+        # ---- ViT: patch-embed GEMM (+bias, + position table broadcast over the batch) ----
+        # step 0 (patchify) and the table pointer are bound at run time
+        plan.patch_desc = self._gemm(plan, P(pa), w["patch.w"], P(x), M, D, Kp, bias=P(w["patch.b"]), residual=0,
+                                     a_rows=plain(Kp), c_rows=plain(D), r_rows=(D, N, 0), out_f32=True)
+        qscale = (64 ** -0.5) * LOG2E
+        for i in range(cfg.run_depth):
+            o = f"vit.{i}."
+            self._ln(plan, P(x), True, w[o + "ln1.g"], w[o + "ln1.b"], P(xn), None, M, D, cfg.vit_ln_eps)
+            self._gemm(plan, P(xn), w[o + "qkv.w"], P(qkv), M, 3 * D, D, bias=P(w[o + "qkv.b"]),
+                       a_rows=plain(D), c_rows=plain(3 * D), scale_cols=D, scale=qscale)
+            self._attn(plan, P(qkv), P(qkv) + 2 * D, P(qkv) + 4 * D, P(att), B, Hv, N, N,
+                       3 * D, 3 * D, 3 * D, D, N * 3 * D, N * 3 * D, N * 3 * D, N * D)
+            self._gemm(plan, P(att), w[o + "proj.w"], P(x), M, D, D, bias=P(w[o + "proj.b"]), residual=P(x),
+                       a_rows=plain(D), c_rows=plain(D), r_rows=plain(D), out_f32=True)
+            self._ln(plan, P(x), True, w[o + "ln2.g"], w[o + "ln2.b"], P(xn), None, M, D, cfg.vit_ln_eps)
+            self._gemm(plan, P(xn), w[o + "fc1.w"], P(hid), M, D * cfg.mlp_ratio, D, bias=P(w[o + "fc1.b"]),
+                       a_rows=plain(D), c_rows=plain(D * cfg.mlp_ratio), act=L.HK_ACT_GELU_ERF)
+            self._gemm(plan, P(hid), w[o + "fc2.w"], P(x), M, D, D * cfg.mlp_ratio, bias=P(w[o + "fc2.b"]),
+                       residual=P(x), a_rows=plain(D * cfg.mlp_ratio), c_rows=plain(D), r_rows=plain(D), out_f32=True)
+        # vision_layernorm (hawkeye_it.py:234) then the K/V projections of every cross layer at once
+        self._ln(plan, P(x), True, w["vln.g"], w["vln.b"], P(xn), None, M, D, cfg.vision_ln_eps)
+        self._gemm(plan, P(xn), w["ckv.w"], P(kvc), M, KVW, D, bias=P(w["ckv.b"]), a_rows=plain(D), c_rows=plain(KVW))
+
+        # ---- Q-Former ----
+        plan.steps.append((self.lib.hk_qformer_embed_ln,
+                           (P(w["query"]), P(w["emb.word"]), P(w["emb.pos"]), P(ids) if Lt > 0 else None,
+                            P(w["emb.ln.g"]), P(w["emb.ln.b"]), P(hf), P(hb), B, nq, Lt, d, w["emb.word"].shape[0],
+                            cfg.qf_ln_eps), "hk_qformer_embed_ln"))
+        qrows = (d, nq, S * d)
+        trows = (d, Lt, S * d)
+        eb = 2  # bytes per bf16
+        ci = 0
+        for i in range(cfg.qf_layers):
+            o = f"qf.{i}."
+            last = i == cfg.qf_layers - 1
+            self._gemm(plan, P(hb), w[o + "qkv.w"], P(qqkv), B * S, 3 * d, d, bias=P(w[o + "qkv.b"]),
+                       a_rows=plain(d), c_rows=plain(3 * d), scale_cols=d, scale=qscale)
+            self._attn(plan, P(qqkv), P(qqkv) + d * eb, P(qqkv) + 2 * d * eb, P(ctx), B, Hq, S, S,
+                       3 * d, 3 * d, 3 * d, d, S * 3 * d, S * 3 * d, S * 3 * d, S * d, key_bias=P(kbias))
+            self._gemm(plan, P(ctx), w[o + "ao.w"], P(tf), B * S, d, d, bias=P(w[o + "ao.b"]), residual=P(hf),
+                       a_rows=plain(d), c_rows=plain(d), r_rows=plain(d), out_f32=True)
+            self._ln(plan, P(tf), True, w[o + "ao.g"], w[o + "ao.bt"], P(ab), P(af), B * S, d, cfg.qf_ln_eps)
+            if i % cfg.cross_attention_freq == 0:
+                self._gemm(plan, P(ab), w[o + "cq.w"], P(cq), B * nq, d, d, bias=P(w[o + "cq.b"]),
+                           a_rows=qrows, c_rows=plain(d), scale_cols=d, scale=qscale)
+                self._attn(plan, P(cq), P(kvc) + ci * 2 * d * eb, P(kvc) + (ci * 2 + 1) * d * eb, P(cctx), B, Hq, nq, N,
+                           d, KVW, KVW, d, nq * d, N * KVW, N * KVW, nq * d)
+                self._gemm(plan, P(cctx), w[o + "co.w"], P(tf), B * nq, d, d, bias=P(w[o + "co.b"]), residual=P(af),
+                           a_rows=plain(d), c_rows=plain(d), r_rows=qrows, out_f32=True)
+                self._ln(plan, P(tf), True, w[o + "co.g"], w[o + "co.bt"], P(cb), P(cf), B * nq, d, cfg.qf_ln_eps)
+                qin_b, qin_f, qin_rows = P(cb), P(cf), plain(d)
+                ci += 1
+            else:
+                qin_b, qin_f, qin_rows = P(ab), P(af), qrows
+            # query-branch FFN (Qformer.py:514-517) -> rows [:, :nq] of the next hidden state
+            self._gemm(plan, qin_b, w[o + "qi.w"], P(fh), B * nq, inter, d, bias=P(w[o + "qi.b"]),
+                       a_rows=qin_rows, c_rows=plain(inter), act=L.HK_ACT_GELU_ERF)
+            self._gemm(plan, P(fh), w[o + "qo.w"], P(tf), B * nq, d, inter, bias=P(w[o + "qo.b"]), residual=qin_f,
+                       a_rows=plain(inter), c_rows=plain(d), r_rows=qin_rows, out_f32=True)
+            self._ln(plan, P(tf), True, w[o + "qo.g"], w[o + "qo.bt"], P(hb), P(hf), B * nq, d, cfg.qf_ln_eps,
+                     out_rows=qrows)
+            # text-branch FFN (Qformer.py:509-512); its last-layer result is never read (hawkeye_it.py:269)
+            if Lt > 0 and not last:
+                toff = nq * d
+                self._gemm(plan, P(ab) + toff * eb, w[o + "ti.w"], P(fh), B * Lt, inter, d, bias=P(w[o + "ti.b"]),
+                           a_rows=trows, c_rows=plain(inter), act=L.HK_ACT_GELU_ERF)
+                self._gemm(plan, P(fh), w[o + "to.w"], P(tf), B * Lt, d, inter, bias=P(w[o + "to.b"]),
+                           residual=P(af) + toff * 4, a_rows=plain(inter), c_rows=plain(d), r_rows=trows, out_f32=True)
+                self._ln(plan, P(tf), True, w[o + "to.g"], w[o + "to.bt"], P(hb) + toff * eb, P(hf) + toff * 4,
+                         B * Lt, d, cfg.qf_ln_eps, out_rows=trows)
+        # llama_proj on the query rows (hawkeye_it.py:269)
+        self._gemm(plan, P(hb), w["proj.w"], P(out), B * nq, cfg.llama_hidden, d, bias=P(w["proj.b"]),
+                   a_rows=qrows, c_rows=plain(cfg.llama_hidden), out_f32=True)
+        return plan
+
+    # ------------------------------------------------------------------ run
+    @torch.no_grad()
+    def forward(self, image: torch.Tensor, input_ids: Optional[torch.Tensor], text_mask: Optional[torch.Tensor],
+                pos_embed: torch.Tensor) -> torch.Tensor:
+        """image [B,T,3,H,W] fp32 on the engine's GPU; input_ids/text_mask [B,Lt] int64 (or None);
+        pos_embed fp32 [N,D] on the GPU (the table the caller's encoder holds for this T).
+        Returns fp32 [B, n_query, llama_hidden] -- a view of the plan's output buffer."""
+        cfg = self.cfg
+        if not self.w:
+            raise RuntimeError("HipEncoderEngine: load_state_dict() has not been called")
+        if image.dim() != 5 or image.shape[2] != 3:
+            raise RuntimeError(f"image must be [B,T,3,H,W], got {tuple(image.shape)}")
+        B, T, _, H, W = image.shape
+        if H != cfg.img_size or W != cfg.img_size:
+            raise RuntimeError(f"image must be {cfg.img_size}x{cfg.img_size}, got {H}x{W}")
+        if image.device != self.device:
+            raise RuntimeError(f"image is on {image.device}, engine on {self.device}")
+        if image.dtype != torch.float32 or not image.is_contiguous():
+            image = image.float().contiguous()
+        Lt = 0 if input_ids is None else int(input_ids.shape[1])
+        N = T * cfg.patches_per_frame
+        if pos_embed.shape[-2:] != (N, cfg.encoder_embed_dim) or pos_embed.dtype != torch.float32 or \
+                pos_embed.device != self.device or not pos_embed.is_contiguous():
+            raise RuntimeError(f"pos_embed must be a contiguous fp32 [{N},{cfg.encoder_embed_dim}] tensor on {self.device}")
+        key = (B, T, Lt)
+        plan = self.plans.get(key)
+        if plan is None:
+            plan = self._build_plan(B, T, Lt)
+            self.plans[key] = plan
+        ws = plan.ws
+        nq = cfg.n_query
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            if Lt > 0:
+                ws["ids"].copy_(input_ids, non_blocking=True)
+                kb = ws["kbias"]
+                kb[:, :nq].zero_()
+                # (1 - mask) * -10000 (Qformer.py:834); query columns are never masked (hawkeye_it.py:250)
+                kb[:, nq:].copy_((1.0 - text_mask.to(device=self.device, dtype=torch.float32)) * -10000.0)
+            else:
+                ws["kbias"].zero_()
+            L.check(self.lib.hk_patchify_bf16(image.data_ptr(), ws["patches"].data_ptr(), B, T, H, W, cfg.patch_size,
+                                              stream), "hk_patchify_bf16")
+            plan.patch_desc.residual = pos_embed.data_ptr()
+            for fn, args, name in plan.steps:
+                rc = fn(*args, stream)
+                if rc != 0:
+                    L.check(rc, name)
+        return ws["out"].view(B, nq, cfg.llama_hidden)
+
+    def workspace_bytes(self, B: int, T: int, Lt: int) -> int:
+        plan = self.plans.get((B, T, Lt))
+        return 0 if plan is None else sum(t.numel() * t.element_size() for t in plan.ws.values())
+
+
+def flops_per_clip(cfg: EncoderConfig, T: int, Lt: int) -> float:
+    """Algorithmic FLOPs of one clip (2 flops per MAC, softmax/LN/GELU excluded)."""
+    N = T * cfg.patches_per_frame
+    D, d = cfg.encoder_embed_dim, cfg.qf_hidden
+    S = cfg.n_query + Lt
+    nq = cfg.n_query
+    inter = cfg.qf_intermediate
+    Hm = D * cfg.mlp_ratio
+    f_vit = 2 * N * cfg.patch_k * D + cfg.run_depth * (2 * N * D * 3 * D + 4 * N * N * D + 2 * N * D * D + 4 * N * D * Hm)
+    n_cross = len([i for i in range(cfg.qf_layers) if i % cfg.cross_attention_freq == 0])
+    f_qf = cfg.qf_layers * (8 * S * d * d + 4 * S * S * d + 4 * nq * d * inter + 4 * Lt * d * inter) + \
+        n_cross * (4 * nq * d * d + 4 * N * D * d + 4 * nq * N * d)
+    f_proj = 2 * nq * d * cfg.llama_hidden
+    return float(f_vit + f_qf + f_proj)

@@ -1,0 +1,86 @@
+"""ctypes binding of libhawkeye_hip.so (include/hawkeye_hip.h).
+
+The library is built in-tree by `make -C hawkeye_amd/csrc` (or
+__graft_entry__.build()).  There is no fallback: if the shared object is
+missing, load() raises, and every op in hawkeye_amd.ops goes through load().
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhawkeye_hip.so")
+
+HK_ACT_NONE, HK_ACT_GELU_ERF = 0, 1
+HK_DT_BF16, HK_DT_F32 = 0, 1
+
+
+class HkRows(C.Structure):
+    _fields_ = [("ld", C.c_int64), ("rows_per_batch", C.c_int64), ("batch_stride", C.c_int64)]
+
+
+class HkGemmDesc(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p), ("C", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("a_rows", HkRows), ("ldw", C.c_int64), ("c_rows", HkRows), ("r_rows", HkRows),
+        ("act", C.c_int32), ("out_dtype", C.c_int32), ("scale_cols", C.c_int32), ("scale", C.c_float),
+    ]
+
+
+class HkAttnDesc(C.Structure):
+    _fields_ = [
+        ("Q", C.c_void_p), ("K", C.c_void_p), ("V", C.c_void_p), ("O", C.c_void_p), ("key_bias", C.c_void_p),
+        ("B", C.c_int32), ("H", C.c_int32), ("Nq", C.c_int32), ("Nk", C.c_int32),
+        ("ldq", C.c_int64), ("ldk", C.c_int64), ("ldv", C.c_int64), ("ldo", C.c_int64),
+        ("bsq", C.c_int64), ("bsk", C.c_int64), ("bsv", C.c_int64), ("bso", C.c_int64),
+    ]
+
+
+# every symbol include/hawkeye_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "hk_gemm_bf16": (C.c_int, [C.POINTER(HkGemmDesc), C.c_void_p]),
+    "hk_flash_attn_bf16": (C.c_int, [C.POINTER(HkAttnDesc), C.c_void_p]),
+    "hk_layernorm": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.POINTER(HkRows), C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
+    "hk_patchify_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                   C.c_void_p]),
+    "hk_qformer_embed_ln": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                      C.c_float, C.c_void_p]),
+    "hk_cast_f32_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "hk_version": (C.c_int, []),
+    "hk_arch": (C.c_char_p, []),
+    "hk_last_error": (C.c_size_t, [C.c_char_p, C.c_size_t]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libhawkeye_hip.so; raises (never falls back) when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension is not built "
+            "(run `make -C hawkeye_amd/csrc` or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "hawkeye_amd has no CPU or PyTorch fallback for the encode_img path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(512)
+    load().hk_last_error(buf, 512)
+    return buf.value.decode(errors="replace")
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (code {rc}): {last_error()}")

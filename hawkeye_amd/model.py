@@ -1,0 +1,298 @@
+"""Drop-in host-side mirror of the reference's encode_img surface.
+
+`HawkEyeEncoder` exposes exactly what tasks/test.py, tasks/test_recursive_grounding.py,
+tasks/train_it.py and demo.ipynb touch on `HawkEye_it` for this path:
+
+  * the attribute tree and state-dict keys of models/hawkeye_it.py:57-80,183-185
+    (`vision_encoder.encoder.{patch_embed.proj,blocks.N.*}`, `vision_layernorm`,
+    `qformer.bert.*`, `query_tokens`, `extra_query_tokens`, `llama_proj`), so
+    `load_state_dict(torch.load("hawkeye.pth"), strict=False)` works unchanged and
+    silently drops the checkpoint's 24th ViT block like the reference does;
+  * `vision_encoder.encoder.pos_embed` / `.img_pos_embed` as plain assignable
+    tensors read at call time (demo.ipynb cell 6; vit.py:304-307);
+  * `encode_img(image, instruction) -> (inputs_llama [B,96,4096], use_image)`
+    (hawkeye_it.py:219-270), `query_tokens` registered first so `.device`
+    (blip2.py:32-34) follows it, `set_device_ids`, `.tokenizer`.
+
+The modules below are parameter containers only: they have no forward of their
+own.  All arithmetic runs in libhawkeye_hip.so through HipEncoderEngine; there
+is no PyTorch or CPU fallback, and encode_img raises if the image is not on an
+MI355X.
+"""
+from types import SimpleNamespace
+from typing import Optional, Sequence, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from . import posembed
+from .config import EncoderConfig
+from .engine import HipEncoderEngine
+
+
+class _NoForward(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover - guard
+        raise RuntimeError(f"{type(self).__name__} is a parameter container; run HawkEyeEncoder.encode_img")
+
+
+class _Attention(_NoForward):          # vit.py:57-79
+    def __init__(self, dim):
+        super().__init__()
+        self.qkv = nn.Linear(dim, dim * 3, bias=False)
+        self.q_bias = nn.Parameter(torch.zeros(dim))
+        self.v_bias = nn.Parameter(torch.zeros(dim))
+        self.proj = nn.Linear(dim, dim)
+
+
+class _Mlp(_NoForward):                # vit.py:38-46
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+
+class _Block(_NoForward):              # vit.py:103-122 (init_values=0 => no gamma_1/gamma_2)
+    def __init__(self, dim, hidden, eps):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=eps)
+        self.attn = _Attention(dim)
+        self.norm2 = nn.LayerNorm(dim, eps=eps)
+        self.mlp = _Mlp(dim, hidden)
+
+
+class _PatchEmbed(_NoForward):         # vit.py:134-150
+    def __init__(self, cfg: EncoderConfig):
+        super().__init__()
+        p = cfg.patch_size
+        self.proj = nn.Conv3d(3, cfg.encoder_embed_dim, kernel_size=(1, p, p), stride=(1, p, p))
+
+
+class _VitEncoder(_NoForward):         # vit.py:244-292
+    def __init__(self, cfg: EncoderConfig):
+        super().__init__()
+        D = cfg.encoder_embed_dim
+        self.patch_embed = _PatchEmbed(cfg)
+        self.depth = cfg.run_depth
+        # plain tensor attributes, not buffers/parameters (vit.py:278-279)
+        self.pos_embed = posembed.video_pos_embed(cfg.num_frames, cfg.patches_per_frame, D, cfg.ckpt_num_frame)
+        self.img_pos_embed = posembed.image_pos_embed(cfg.patches_per_frame, D)
+        self.blocks = nn.ModuleList([_Block(D, D * cfg.mlp_ratio, cfg.vit_ln_eps) for _ in range(self.depth)])
+        self.norm = nn.Identity()
+
+
+class _VisionTransformer(_NoForward):  # vit.py:327-384
+    def __init__(self, cfg: EncoderConfig):
+        super().__init__()
+        self.encoder = _VitEncoder(cfg)
+
+
+class _BertEmbeddings(_NoForward):     # Qformer.py:52-78
+    def __init__(self, cfg: EncoderConfig):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(cfg.qf_vocab, cfg.qf_hidden, padding_idx=0)
+        self.position_embeddings = nn.Embedding(cfg.qf_max_pos, cfg.qf_hidden)
+        self.LayerNorm = nn.LayerNorm(cfg.qf_hidden, eps=cfg.qf_ln_eps)
+        self.register_buffer("position_ids", torch.arange(cfg.qf_max_pos).expand((1, -1)))
+
+
+class _BertSelfAttention(_NoForward):  # Qformer.py:124-146
+    def __init__(self, d, kv_width):
+        super().__init__()
+        self.query = nn.Linear(d, d)
+        self.key = nn.Linear(kv_width, d)
+        self.value = nn.Linear(kv_width, d)
+
+
+class _BertDenseLN(_NoForward):        # Qformer.py:305-311 / 393-399
+    def __init__(self, d_in, d, eps):
+        super().__init__()
+        self.dense = nn.Linear(d_in, d)
+        self.LayerNorm = nn.LayerNorm(d, eps=eps)
+
+
+class _BertAttention(_NoForward):      # Qformer.py:321-326
+    def __init__(self, d, kv_width, eps):
+        super().__init__()
+        self.self = _BertSelfAttention(d, kv_width)
+        self.output = _BertDenseLN(d, d, eps)
+
+
+class _BertIntermediate(_NoForward):   # Qformer.py:378-385
+    def __init__(self, d, inter):
+        super().__init__()
+        self.dense = nn.Linear(d, inter)
+
+
+class _BertLayer(_NoForward):          # Qformer.py:409-433
+    def __init__(self, cfg: EncoderConfig, layer_num: int):
+        super().__init__()
+        d, eps = cfg.qf_hidden, cfg.qf_ln_eps
+        self.attention = _BertAttention(d, d, eps)
+        self.has_cross_attention = layer_num % cfg.cross_attention_freq == 0
+        if self.has_cross_attention:
+            self.crossattention = _BertAttention(d, cfg.encoder_embed_dim, eps)
+        self.intermediate = _BertIntermediate(d, cfg.qf_intermediate)
+        self.output = _BertDenseLN(cfg.qf_intermediate, d, eps)
+        self.intermediate_query = _BertIntermediate(d, cfg.qf_intermediate)
+        self.output_query = _BertDenseLN(cfg.qf_intermediate, d, eps)
+
+
+class _BertEncoder(_NoForward):        # Qformer.py:520-526
+    def __init__(self, cfg: EncoderConfig):
+        super().__init__()
+        self.layer = nn.ModuleList([_BertLayer(cfg, i) for i in range(cfg.qf_layers)])
+
+
+class _BertModel(_NoForward):          # Qformer.py:710-730
+    def __init__(self, cfg: EncoderConfig):
+        super().__init__()
+        self.embeddings = _BertEmbeddings(cfg)
+        self.encoder = _BertEncoder(cfg)
+
+
+class _QFormer(_NoForward):            # Qformer.py:1001 BertLMHeadModel with cls=None (hawkeye_it.py:73)
+    def __init__(self, cfg: EncoderConfig):
+        super().__init__()
+        self.config = SimpleNamespace(hidden_size=cfg.qf_hidden, num_hidden_layers=cfg.qf_layers,
+                                      num_attention_heads=cfg.qf_heads, intermediate_size=cfg.qf_intermediate,
+                                      vocab_size=cfg.qf_vocab, encoder_width=cfg.encoder_embed_dim,
+                                      query_length=cfg.num_query_token, cross_attention_freq=cfg.cross_attention_freq)
+        self.bert = _BertModel(cfg)
+        self.cls = None
+
+    def resize_token_embeddings(self, n: int):
+        """hawkeye_it.py:72 -- keep existing rows, N(0, 0.02) for new ones."""
+        old = self.bert.embeddings.word_embeddings
+        if n == old.num_embeddings:
+            return old
+        new = nn.Embedding(n, old.embedding_dim, padding_idx=0).to(old.weight.device, old.weight.dtype)
+        new.weight.data.normal_(mean=0.0, std=0.02)
+        k = min(n, old.num_embeddings)
+        new.weight.data[:k] = old.weight.data[:k]
+        self.bert.embeddings.word_embeddings = new
+        self.config.vocab_size = n
+        return new
+
+
+def disabled_train(self, mode=True):   # blip2.py:90-93
+    return self
+
+
+class HawkEyeEncoder(nn.Module):
+    """The hot-path half of HawkEye_it (models/hawkeye_it.py:15-270) on MI355X."""
+
+    def __init__(self, cfg: EncoderConfig = EncoderConfig(), tokenizer=None, max_txt_len: int = 512,
+                 out_dtype: torch.dtype = torch.float16):
+        super().__init__()
+        self.cfg = cfg
+        # registered first: Blip2Base.device is "device of the first parameter" (blip2.py:32-34)
+        self.query_tokens = nn.Parameter(torch.zeros(1, cfg.num_query_token, cfg.qf_hidden))
+        self.query_tokens.data.normal_(mean=0.0, std=0.02)
+        self.vision_encoder = _VisionTransformer(cfg)
+        self.vision_layernorm = nn.LayerNorm(cfg.encoder_embed_dim, eps=cfg.vision_ln_eps)
+        self.qformer = _QFormer(cfg)
+        self.extra_num_query_token = cfg.extra_num_query_token
+        if cfg.extra_num_query_token > 0:
+            self.extra_query_tokens = nn.Parameter(torch.zeros(1, cfg.extra_num_query_token, cfg.qf_hidden))
+        self.llama_proj = nn.Linear(cfg.qf_hidden, cfg.llama_hidden)
+        self.tokenizer = tokenizer
+        self.max_txt_len = max_txt_len
+        self.qformer_text_input = True
+        self.low_resource = False
+        self.out_dtype = out_dtype        # the reference returns fp16 under its autocast (blip2.py:42)
+        self.devices = [torch.device("cuda", 0), torch.device("cuda", 0)]
+        self._engine: Optional[HipEncoderEngine] = None
+        self._engine_key = None
+        self._table_cache = {}
+
+    # ---- reference module protocol -------------------------------------------------
+    @property
+    def device(self):
+        return list(self.parameters())[0].device
+
+    def set_device_ids(self, device_ids):           # hawkeye_it.py:197-211
+        assert isinstance(device_ids, list) and 1 <= len(device_ids) <= 2
+        if len(device_ids) == 1:
+            device_ids = [device_ids[0], device_ids[0]]
+        if device_ids[0] != device_ids[1]:
+            raise NotImplementedError("two-device ViT placement is not needed on a 288 GB MI355X; use one device id")
+        self.devices = [torch.device("cuda", i) if isinstance(i, int) else torch.device(i) for i in device_ids]
+        self.to(self.devices[0])
+
+    @classmethod
+    def from_reference_config(cls, config, **kw):
+        """Build from the reference's model config dict (configs/config.json `model`)."""
+        ve = config["vision_encoder"]
+        cfg = EncoderConfig(
+            img_size=ve["img_size"], patch_size=ve["patch_size"], encoder_embed_dim=ve["encoder_embed_dim"],
+            encoder_depth=ve["encoder_depth"], return_index=ve.get("return_index", -1),
+            encoder_num_heads=ve["encoder_num_heads"], num_frames=ve["num_frames"],
+            num_query_token=config["num_query_token"], extra_num_query_token=config.get("extra_num_query_token", 32))
+        return cls(cfg, max_txt_len=config.get("max_txt_len", 32), **kw)
+
+    # ---- engine plumbing -----------------------------------------------------------
+    def _weights_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def sync_engine(self, force: bool = False) -> HipEncoderEngine:
+        """(Re)pack device weights when a parameter was replaced or modified in place."""
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError("HawkEyeEncoder.encode_img needs the model on an MI355X (model.to('cuda')); "
+                               "there is no CPU path")
+        key = (str(dev), self._weights_key())
+        if force or self._engine is None or self._engine_key != key:
+            if self._engine is None or self._engine.device != dev:
+                self._engine = HipEncoderEngine(self.cfg, dev)
+            self._engine.load_state_dict(self.state_dict())
+            self._engine_key = key
+        return self._engine
+
+    def _table(self, use_image: bool, n_tokens: int, dev) -> torch.Tensor:
+        enc = self.vision_encoder.encoder
+        t = enc.img_pos_embed if use_image else enc.pos_embed     # read at call time (vit.py:304-307)
+        if t.shape[-2] != n_tokens:
+            raise RuntimeError(
+                f"pos_embed has {t.shape[-2]} positions but the clip has {n_tokens} tokens "
+                "(assign vision_encoder.encoder.pos_embed for this frame count, as demo.ipynb does)")
+        key = (use_image, t.data_ptr(), t._version, tuple(t.shape), str(dev))
+        hit = self._table_cache.get(use_image)
+        if hit is None or hit[0] != key:
+            dt = t.detach().reshape(n_tokens, -1).to(device=dev, dtype=torch.float32).contiguous()
+            self._table_cache[use_image] = (key, dt, t)   # keep `t` alive so data_ptr cannot be recycled
+            return dt
+        return hit[1]
+
+    def _tokenize(self, instruction, B: int, dev) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+        if isinstance(instruction, (tuple, list)) and len(instruction) == 2 and torch.is_tensor(instruction[0]):
+            ids, mask = instruction                  # pre-tokenised (input_ids, attention_mask)
+        else:
+            if self.tokenizer is None:
+                raise RuntimeError("encode_img got text but model.tokenizer is None; assign a BertTokenizer-compatible "
+                                   "callable or pass (input_ids, attention_mask) tensors")
+            tok = self.tokenizer(instruction, padding="longest", truncation=True, max_length=self.max_txt_len,
+                                 return_tensors="pt")     # hawkeye_it.py:243-249
+            ids, mask = tok.input_ids, tok.attention_mask
+        if ids.shape[0] == 1 and B > 1:
+            ids, mask = ids.expand(B, -1), mask.expand(B, -1)
+        if ids.shape[0] != B:
+            raise RuntimeError(f"instruction batch {ids.shape[0]} does not match image batch {B}")
+        return ids.to(dev, torch.int64).contiguous(), mask.to(dev, torch.int64).contiguous()
+
+    # ---- the hot path --------------------------------------------------------------
+    @torch.no_grad()
+    def encode_img(self, image: torch.Tensor, instruction: Union[str, Sequence[str], Tuple[torch.Tensor, torch.Tensor]]):
+        """hawkeye_it.py:219-270.  image [B,T,3,H,W] float on the model's GPU."""
+        device = image.device
+        eng = self.sync_engine()
+        if device != eng.device:
+            image = image.to(eng.device)
+        B, T = image.shape[0], image.shape[1]
+        use_image = True if T == 1 else False                       # :227
+        table = self._table(use_image, T * self.cfg.patches_per_frame, eng.device)
+        ids = mask = None
+        if self.qformer_text_input:
+            ids, mask = self._tokenize(instruction, B, eng.device)
+        out = eng.forward(image, ids, mask, table)
+        out = out.to(self.out_dtype) if self.out_dtype != torch.float32 else out.clone()
+        return out.to(device), use_image

@@ -1,0 +1,180 @@
+"""Tensor-level wrappers over the C ABI (include/hawkeye_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream;
+every function passes raw pointers to libhawkeye_hip.so and raises
+RuntimeError on a non-zero return code.  Nothing in this file computes.
+"""
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import lib as L
+
+Rows = Tuple[int, int, int]  # (ld, rows_per_batch, batch_stride) in elements; rows_per_batch 0 = plain
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _need(t: torch.Tensor, dtype, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (hawkeye_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name} must be {dtype}, got {t.dtype}")
+
+
+def gemm_desc(A, W, C_out, M, N, K, *, bias=None, residual=None, a_rows: Rows, c_rows: Rows,
+              r_rows: Rows = (0, 0, 0), ldw=None, act=L.HK_ACT_NONE, out_f32=False, scale_cols=0,
+              scale=1.0) -> L.HkGemmDesc:
+    """Raw-pointer descriptor; A/W/C_out/bias/residual are integer device addresses."""
+    d = L.HkGemmDesc()
+    d.A, d.W, d.bias, d.residual, d.C = A, W, bias, residual, C_out
+    d.M, d.N, d.K = M, N, K
+    d.a_rows = L.HkRows(*a_rows)
+    d.ldw = K if ldw is None else ldw
+    d.c_rows = L.HkRows(*c_rows)
+    d.r_rows = L.HkRows(*r_rows)
+    d.act = act
+    d.out_dtype = L.HK_DT_F32 if out_f32 else L.HK_DT_BF16
+    d.scale_cols = scale_cols
+    d.scale = scale
+    return d
+
+
+def run_gemm(d: L.HkGemmDesc):
+    L.check(L.load().hk_gemm_bf16(C.byref(d), _stream()), "hk_gemm_bf16")
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
+           residual: Optional[torch.Tensor] = None, act: str = "none", out_dtype=torch.bfloat16,
+           scale_cols: int = 0, scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = act((x @ w.T + bias) * colscale) + residual; x [M,K] bf16, w [N,K] bf16."""
+    _need(x, torch.bfloat16, "x")
+    _need(w, torch.bfloat16, "w")
+    M, K = x.shape
+    N = w.shape[0]
+    if x.stride(1) != 1 or w.stride(1) != 1 or w.shape[1] != K:
+        raise RuntimeError("linear: x and w must be K-contiguous with matching K")
+    if bias is not None:
+        _need(bias, torch.float32, "bias")
+    if residual is not None:
+        _need(residual, torch.float32, "residual")
+        if residual.shape != (M, N) or residual.stride(1) != 1:
+            raise RuntimeError("linear: residual must be [M,N] row-major fp32")
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=x.device)
+    _need(out, out_dtype, "out")
+    d = gemm_desc(x.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, K, bias=_ptr(bias), residual=_ptr(residual),
+                  a_rows=(x.stride(0), 0, 0), c_rows=(out.stride(0), 0, 0),
+                  r_rows=(residual.stride(0), 0, 0) if residual is not None else (0, 0, 0), ldw=w.stride(0),
+                  act=L.HK_ACT_GELU_ERF if act == "gelu" else L.HK_ACT_NONE, out_f32=out_dtype == torch.float32,
+                  scale_cols=scale_cols, scale=scale)
+    run_gemm(d)
+    return out
+
+
+def attn_desc(Q, K, V, O, B, H, Nq, Nk, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, key_bias=None) -> L.HkAttnDesc:
+    d = L.HkAttnDesc()
+    d.Q, d.K, d.V, d.O, d.key_bias = Q, K, V, O, key_bias
+    d.B, d.H, d.Nq, d.Nk = B, H, Nq, Nk
+    d.ldq, d.ldk, d.ldv, d.ldo = ldq, ldk, ldv, ldo
+    d.bsq, d.bsk, d.bsv, d.bso = bsq, bsk, bsv, bso
+    return d
+
+
+def run_attn(d: L.HkAttnDesc):
+    L.check(L.load().hk_flash_attn_bf16(C.byref(d), _stream()), "hk_flash_attn_bf16")
+
+
+def flash_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, key_bias: Optional[torch.Tensor] = None,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q [B,Nq,H,64], k/v [B,Nk,H,64] bf16 views (last two dims dense), q pre-scaled by scale*log2(e).
+    key_bias: optional fp32 [B,Nk] additive (natural-log units).  Returns [B,Nq,H,64] bf16."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        _need(t, torch.bfloat16, n)
+        if t.dim() != 4 or t.shape[3] != 64 or t.stride(3) != 1 or t.stride(2) != 64:
+            raise RuntimeError(f"flash_attention: {n} must be [B,N,H,64] with dense (H,64) dims")
+    B, Nq, H, _ = q.shape
+    Nk = k.shape[1]
+    if out is None:
+        out = torch.empty((B, Nq, H, 64), dtype=torch.bfloat16, device=q.device)
+    if key_bias is not None:
+        _need(key_bias, torch.float32, "key_bias")
+        if key_bias.shape != (B, Nk) or not key_bias.is_contiguous():
+            raise RuntimeError("flash_attention: key_bias must be contiguous [B,Nk]")
+    d = attn_desc(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, H, Nq, Nk,
+                  q.stride(1), k.stride(1), v.stride(1), out.stride(1),
+                  q.stride(0), k.stride(0), v.stride(0), out.stride(0), _ptr(key_bias))
+    run_attn(d)
+    return out
+
+
+def layernorm_raw(x_ptr, in_f32: bool, add_ptr, gamma_ptr, beta_ptr, out_b_ptr, out_f_ptr, rows: int, D: int,
+                  eps: float, out_rows: Optional[Rows] = None):
+    orow = C.byref(L.HkRows(*out_rows)) if out_rows is not None else None
+    L.check(L.load().hk_layernorm(x_ptr, L.HK_DT_F32 if in_f32 else L.HK_DT_BF16, add_ptr, gamma_ptr, beta_ptr,
+                                  out_b_ptr, out_f_ptr, orow, rows, D, eps, _stream()), "hk_layernorm")
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, *,
+              add: Optional[torch.Tensor] = None, want_bf16=True, want_f32=False):
+    """LayerNorm over the last dim of x [rows, D] (fp32 or bf16); returns (bf16 | None, fp32 | None)."""
+    if x.dtype not in (torch.float32, torch.bfloat16) or not x.is_cuda or not x.is_contiguous():
+        raise RuntimeError("layernorm: x must be a contiguous fp32/bf16 GPU tensor")
+    _need(gamma, torch.float32, "gamma")
+    _need(beta, torch.float32, "beta")
+    rows, D = x.shape
+    ob = torch.empty((rows, D), dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    of = torch.empty((rows, D), dtype=torch.float32, device=x.device) if want_f32 else None
+    if add is not None:
+        _need(add, torch.float32, "add")
+        if add.shape != x.shape or not add.is_contiguous():
+            raise RuntimeError("layernorm: add must match x")
+    layernorm_raw(x.data_ptr(), x.dtype == torch.float32, _ptr(add), gamma.data_ptr(), beta.data_ptr(), _ptr(ob),
+                  _ptr(of), rows, D, eps)
+    return ob, of
+
+
+def patchify(clip: torch.Tensor, patch: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """clip [B,T,3,H,W] fp32 contiguous -> [B*T*(H/p)*(W/p), 3*p*p] bf16."""
+    _need(clip, torch.float32, "clip")
+    if clip.dim() != 5 or clip.shape[2] != 3 or not clip.is_contiguous():
+        raise RuntimeError("patchify: clip must be contiguous [B,T,3,H,W]")
+    B, T, _, H, W = clip.shape
+    rows = B * T * (H // patch) * (W // patch)
+    if out is None:
+        out = torch.empty((rows, 3 * patch * patch), dtype=torch.bfloat16, device=clip.device)
+    L.check(L.load().hk_patchify_bf16(clip.data_ptr(), out.data_ptr(), B, T, H, W, patch, _stream()),
+            "hk_patchify_bf16")
+    return out
+
+
+def qformer_embed_ln(query_tokens, word_emb, pos_emb, input_ids, gamma, beta, eps, out_f32, out_bf16):
+    """query_tokens [nq,d], word_emb [V,d], pos_emb [P,d] fp32; input_ids [B,Lt] int64 (or None)."""
+    nq, d = query_tokens.shape
+    B, S, _ = out_f32.shape
+    Lt = S - nq
+    if Lt > 0:
+        _need(input_ids, torch.int64, "input_ids")
+        if input_ids.shape != (B, Lt) or not input_ids.is_contiguous():
+            raise RuntimeError("qformer_embed_ln: input_ids must be contiguous [B,Lt]")
+        if Lt > pos_emb.shape[0]:
+            raise RuntimeError("qformer_embed_ln: instruction longer than the position table")
+    L.check(L.load().hk_qformer_embed_ln(
+        query_tokens.data_ptr(), _ptr(word_emb), _ptr(pos_emb), _ptr(input_ids) if Lt > 0 else None,
+        gamma.data_ptr(), beta.data_ptr(), out_f32.data_ptr(), out_bf16.data_ptr(), B, nq, Lt, d,
+        word_emb.shape[0] if word_emb is not None else 1, eps, _stream()), "hk_qformer_embed_ln")
+
+
+def cast_bf16(x: torch.Tensor) -> torch.Tensor:
+    _need(x, torch.float32, "x")
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    L.check(L.load().hk_cast_f32_bf16(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "hk_cast_f32_bf16")
+    return out

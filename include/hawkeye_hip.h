@@ -1,0 +1,129 @@
+/*
+ * libhawkeye_hip.so -- C ABI of the MI355X (gfx950) encode_img kernels.
+ *
+ * The reference (yellow-binary-tree/HawkEye) has no FFI: the "operators" on its
+ * hot path are the PyTorch ops listed in SURVEY.md §2.1.  Each entry point
+ * below replaces one group of those ops and cites the reference call sites it
+ * stands in for.  Conventions:
+ *   - the caller owns every buffer (inputs, outputs, workspace) and passes raw
+ *     device pointers; the library never allocates, frees or synchronises;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*);
+ *   - tensors are row-major; bf16 tensors and fp32 rows must be 16-byte aligned;
+ *   - return value 0 = success, otherwise an HK_E* code; hk_last_error() holds
+ *     the text of the last failure on the calling thread.
+ */
+#ifndef HAWKEYE_HIP_H
+#define HAWKEYE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HK_OK 0
+#define HK_EINVAL 1   /* bad shape / alignment / null pointer */
+#define HK_ELAUNCH 2  /* hipGetLastError() after a launch was not hipSuccess */
+
+#define HK_ACT_NONE 0
+#define HK_ACT_GELU_ERF 1
+
+#define HK_DT_BF16 0
+#define HK_DT_F32 1
+
+/* Row addressing shared by the GEMM operands: logical row m of an operand lives at
+ *   base + (m / rows_per_batch) * batch_stride + (m % rows_per_batch) * ld   (elements)
+ * rows_per_batch == 0 means "plain": base + m * ld.  This lets one launch address
+ * the query rows [:, :96] of a [B,S,768] Q-Former buffer (Qformer.py:463) or
+ * broadcast the [N,1024] position table over the batch (vit.py:307). */
+typedef struct hk_rows {
+    int64_t ld;
+    int64_t rows_per_batch;
+    int64_t batch_stride;
+} hk_rows;
+
+/* C = act((A . W^T + bias) * colscale) + residual
+ *   A [M,K] bf16, W [N,K] bf16 (nn.Linear / flattened Conv3d weight layout), bias [N] fp32 or NULL,
+ *   residual fp32 or NULL, C bf16 or fp32 (out_dtype).  fp32 accumulation on MFMA.
+ *   Columns n < scale_cols are multiplied by `scale` after the bias (used to fold the
+ *   attention scale into Q: vit.py:91, Qformer.py:257).
+ * Replaces: F.linear qkv vit.py:87; proj vit.py:98 + residual vit.py:126; fc1+GELU vit.py:49-50;
+ *   fc2 vit.py:52 + residual vit.py:127; Conv3d patch-embed vit.py:158 + pos table vit.py:307;
+ *   BERT query/key/value/dense Qformer.py:199-211,314,388,402; llama_proj hawkeye_it.py:269.
+ * Requires K % 64 == 0, N % 16 == 0. */
+typedef struct hk_gemm_desc {
+    const void* A;
+    const void* W;
+    const float* bias;
+    const float* residual;
+    void* C;
+    int32_t M, N, K;
+    hk_rows a_rows;
+    int64_t ldw;
+    hk_rows c_rows;
+    hk_rows r_rows;
+    int32_t act;        /* HK_ACT_* */
+    int32_t out_dtype;  /* HK_DT_* */
+    int32_t scale_cols;
+    float scale;
+} hk_gemm_desc;
+
+int hk_gemm_bf16(const hk_gemm_desc* d, void* stream);
+
+/* Fused softmax(Q K^T + key_bias) V, head size 64, fp32 online softmax, bf16 in/out.
+ *   Q [B,Nq,H,64], K/V [B,Nk,H,64], O [B,Nq,H,64] addressed through element strides
+ *   (token stride ld*, batch stride bs*; head h at column h*64).  Q must already carry
+ *   softmax_scale * log2(e) (folded into the producing GEMM); key_bias is an optional
+ *   fp32 [B,Nk] additive term in natural-log units (the -10000 mask of Qformer.py:834).
+ * Replaces: vit.py:91-97 (q*scale, q k^T, softmax, @v, transpose/reshape) and
+ *   Qformer.py:218-281 (scores, /sqrt(d), +mask, softmax, context, permute). */
+typedef struct hk_attn_desc {
+    const void* Q;
+    const void* K;
+    const void* V;
+    void* O;
+    const float* key_bias;
+    int32_t B, H, Nq, Nk;
+    int64_t ldq, ldk, ldv, ldo;
+    int64_t bsq, bsk, bsv, bso;
+} hk_attn_desc;
+
+int hk_flash_attn_bf16(const hk_attn_desc* d, void* stream);
+
+/* y = LayerNorm(x [+ add]) * gamma + beta over the last dim (D % 4 == 0, D <= 4096), fp32 statistics.
+ *   x: in_dtype (bf16 | fp32) [rows, D] plain; add: optional fp32 [rows, D] summed before the norm
+ *   (BERT post-LN, Qformer.py:317,405); out_bf16 and/or out_f32 may be NULL; out_rows (may be NULL =
+ *   plain [rows, D]) maps output row m like the GEMM operands, so a [B*nq, d] result can land in
+ *   rows [:, :nq] of a [B, S, d] buffer (the torch.cat of Qformer.py:495).
+ * Replaces: nn.LayerNorm vit.py:108,114 (eps 1e-6); vision_layernorm hawkeye_it.py:234 (eps 1e-12);
+ *   BertSelfOutput/BertOutput LayerNorm Qformer.py:317,405. */
+int hk_layernorm(const void* x, int32_t in_dtype, const float* add, const float* gamma, const float* beta,
+                 void* out_bf16, float* out_f32, const hk_rows* out_rows, int64_t rows, int32_t D, float eps,
+                 void* stream);
+
+/* Patch gather for the per-frame 16x16 patch GEMM: clip [B,T,3,H,W] fp32 (the caller's
+ * layout, tasks/test.py:490-492) -> A [B*T*(H/p)*(W/p), 3*p*p] bf16 with rows ordered (b,t,gy,gx) and
+ * K ordered (c,ky,kx) -- the flattening of Conv3d weight [D,3,1,p,p] (vit.py:146-150,158). */
+int hk_patchify_bf16(const float* clip, void* out, int32_t B, int32_t T, int32_t H, int32_t W, int32_t patch,
+                     void* stream);
+
+/* Q-Former embeddings: rows [0,nq) = query_tokens; rows [nq, nq+Lt) = word_emb[ids] + pos_emb[0..Lt);
+ * LayerNorm(eps) -> out_f32 and out_bf16 [B, nq+Lt, d].  (Qformer.py:97-121; hawkeye_it.py:237-241) */
+int hk_qformer_embed_ln(const float* query_tokens, const float* word_emb, const float* pos_emb,
+                        const int64_t* input_ids, const float* gamma, const float* beta, float* out_f32,
+                        void* out_bf16, int32_t B, int32_t nq, int32_t Lt, int32_t d, int32_t vocab, float eps,
+                        void* stream);
+
+/* fp32 -> bf16 (round-to-nearest-even) copy of n elements; weight packing at load time. */
+int hk_cast_f32_bf16(const float* x, void* out, int64_t n, void* stream);
+
+/* Library identification and last-error text. */
+int hk_version(void);
+const char* hk_arch(void);
+size_t hk_last_error(char* buf, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HAWKEYE_HIP_H */

@@ -1,0 +1,54 @@
+"""CPU checks of the C-ABI boundary: the library loads, exports every symbol
+include/hawkeye_hip.h declares, and rejects bad descriptors without touching a GPU."""
+import ctypes as C
+import os
+import re
+
+from hawkeye_amd import lib as L
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(REPO, "include", "hawkeye_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(hk_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    lib = L.load()
+    names = _declared()
+    assert len(names) >= 9
+    for n in names:
+        assert hasattr(lib, n), n
+        assert n in L.SYMBOLS, f"{n} declared in the header but not bound in hawkeye_amd/lib.py"
+    assert sorted(L.SYMBOLS) == names
+
+
+def test_version_and_arch():
+    lib = L.load()
+    assert lib.hk_version() >= 100
+    assert lib.hk_arch() == b"gfx950"
+
+
+def test_struct_layout_matches_header():
+    # hk_rows: 3 x int64; hk_gemm_desc: 5 ptr, 3 int32 (+pad), rows, int64, rows, rows, 3 int32 + float
+    assert C.sizeof(L.HkRows) == 24
+    assert C.sizeof(L.HkGemmDesc) == 5 * 8 + 16 + 24 + 8 + 24 + 24 + 16
+    assert C.sizeof(L.HkAttnDesc) == 5 * 8 + 16 + 8 * 8
+
+
+def test_bad_descriptors_are_rejected_with_text():
+    lib = L.load()
+    d = L.HkGemmDesc()
+    assert lib.hk_gemm_bf16(C.byref(d), None) == 1
+    assert "null operand" in L.last_error()
+    d.A = d.W = d.C = 4096
+    d.M, d.N, d.K = 16, 16, 48
+    assert lib.hk_gemm_bf16(C.byref(d), None) == 1
+    assert "multiple of 64" in L.last_error()
+    a = L.HkAttnDesc()
+    assert lib.hk_flash_attn_bf16(C.byref(a), None) == 1
+    assert lib.hk_layernorm(None, 0, None, None, None, None, None, None, 4, 64, 1e-6, None) == 1
+    assert lib.hk_patchify_bf16(4096, 4096, 1, 1, 30, 32, 16, None) == 1
+    assert "bad shape" in L.last_error()

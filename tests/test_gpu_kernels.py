@@ -1,0 +1,194 @@
+"""Per-kernel numerics on a real MI355X, through the C ABI, against plain fp32
+PyTorch references evaluated on the same (bf16-rounded) inputs.
+
+Tolerances: the kernels multiply bf16 operands exactly and accumulate in fp32, so a
+GEMM/attention result differs from the fp32 reference only by summation order and by
+the final bf16 rounding of the output (rel 2^-8).  Stated per test.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from hawkeye_amd import ops  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _rand(shape, seed, scale=1.0, dtype=torch.float32):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(DEV).to(dtype)
+
+
+def _rel(a, ref):
+    return ((a.double() - ref.double()).abs().max() / ref.double().abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 1024), (300, 272, 128), (1, 16, 64),
+                                   (100352 // 8, 1024, 1024), (65600, 512, 256), (3136 * 2, 3072, 1024)])
+def test_gemm_plain_bf16_out(M, N, K):
+    x = _rand((M, K), 1, dtype=torch.bfloat16)
+    w = _rand((N, K), 2, 0.05, dtype=torch.bfloat16)
+    b = _rand((N,), 3)
+    out = ops.linear(x, w, b)
+    ref = x.float() @ w.float().t() + b
+    # bf16 output rounding dominates: rel 2^-8 of each element, measured against the max
+    assert _rel(out.float(), ref) < 6e-3
+    # asymmetric-operand orientation check: an exact small-integer problem must be exact
+    xi = torch.randint(-3, 4, (M, K), device=DEV).to(torch.bfloat16)
+    wi = torch.randint(-2, 3, (N, K), device=DEV).to(torch.bfloat16)
+    oi = ops.linear(xi, wi, None, out_dtype=torch.float32)
+    assert torch.equal(oi, xi.float() @ wi.float().t())
+
+
+def test_gemm_epilogues_and_row_maps():
+    M, N, K = 2 * 96, 768, 768
+    B, S, nq = 2, 120, 96
+    hb = _rand((B * S, K), 4, dtype=torch.bfloat16)
+    w = _rand((N, K), 5, 0.03, dtype=torch.bfloat16)
+    bias = _rand((N,), 6)
+    res = _rand((B * S, N), 7)
+    out = torch.zeros((M, N), dtype=torch.float32, device=DEV)
+    d = ops.gemm_desc(hb.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, K, bias=bias.data_ptr(),
+                      residual=res.data_ptr(), a_rows=(K, nq, S * K), c_rows=(N, 0, 0), r_rows=(N, nq, S * N),
+                      out_f32=True, scale_cols=256, scale=0.5)
+    ops.run_gemm(d)
+    a = hb.view(B, S, K)[:, :nq].reshape(M, K).float()
+    ref = a @ w.float().t() + bias
+    ref[:, :256] *= 0.5
+    ref = ref + res.view(B, S, N)[:, :nq].reshape(M, N)
+    assert _rel(out, ref) < 2e-5          # fp32 out: summation order only
+    # GELU(erf) epilogue, bf16 out
+    g = ops.linear(a.to(torch.bfloat16), w, bias, act="gelu")
+    gref = torch.nn.functional.gelu(a @ w.float().t() + bias)
+    assert _rel(g.float(), gref) < 6e-3
+    g32 = ops.linear(a.to(torch.bfloat16), w, bias, act="gelu", out_dtype=torch.float32)
+    assert (g32 - gref).abs().max().item() < 2e-5   # exact-erf GELU to fp32 noise
+    # broadcast residual (position table): rows_per_batch = N tokens, batch_stride = 0
+    ntok = 48
+    tab = _rand((ntok, N), 8)
+    out2 = torch.empty((M, N), dtype=torch.float32, device=DEV)
+    x2 = a.to(torch.bfloat16).contiguous()
+    d2 = ops.gemm_desc(x2.data_ptr(), w.data_ptr(), out2.data_ptr(), M, N, K, bias=bias.data_ptr(),
+                       residual=tab.data_ptr(), a_rows=(K, 0, 0), c_rows=(N, 0, 0), r_rows=(N, ntok, 0), out_f32=True)
+    ops.run_gemm(d2)
+    ref2 = x2.float() @ w.float().t() + bias + tab.repeat(M // ntok, 1)
+    assert _rel(out2, ref2) < 2e-5
+
+
+def test_gemm_rejects_bad_shapes():
+    x = _rand((8, 48), 1, dtype=torch.bfloat16)
+    w = _rand((16, 48), 2, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        ops.linear(x, w)
+
+
+def _attn_ref(q, k, v, key_bias=None):
+    # q is pre-scaled by scale*log2(e): softmax over exp2 == exp of q/log2e
+    s = torch.einsum("bqhd,bkhd->bhqk", q.float(), k.float()) / math.log2(math.e)
+    if key_bias is not None:
+        s = s + key_bias[:, None, None, :]
+    p = s.softmax(-1)
+    return torch.einsum("bhqk,bkhd->bqhd", p, v.float())
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk", [(2, 4, 128, 64), (1, 2, 200, 200), (2, 3, 96, 500), (1, 16, 1568, 1568),
+                                       (3, 12, 108, 108), (1, 1, 1, 1), (2, 2, 33, 65)])
+def test_flash_attention_matches_fp32_softmax(B, H, Nq, Nk):
+    q = _rand((B, Nq, H, 64), 11, 0.6, torch.bfloat16)
+    k = _rand((B, Nk, H, 64), 12, 1.0, torch.bfloat16)
+    v = _rand((B, Nk, H, 64), 13, 1.0, torch.bfloat16)
+    o = ops.flash_attention(q, k, v)
+    ref = _attn_ref(q, k, v)
+    # P is rounded to bf16 before P.V and O to bf16 on store: abs error <= ~2^-8 * max|v|
+    assert (o.float() - ref).abs().max().item() < 2.5e-2
+    assert _rel(o.float(), ref) < 1.5e-2
+
+
+def test_flash_attention_strided_views_and_key_bias():
+    B, S, H = 3, 108, 12
+    d = H * 64
+    qkv = _rand((B, S, 3 * d), 21, 0.5, torch.bfloat16)
+    q = qkv[:, :, :d].unflatten(2, (H, 64))
+    k = qkv[:, :, d:2 * d].unflatten(2, (H, 64))
+    v = qkv[:, :, 2 * d:].unflatten(2, (H, 64))
+    mask = torch.ones(B, S, device=DEV)
+    mask[1, 100:] = 0
+    mask[2, 97:] = 0
+    kb = ((1.0 - mask) * -10000.0).contiguous()
+    o = ops.flash_attention(q, k, v, key_bias=kb)
+    ref = _attn_ref(q, k, v, kb)
+    assert (o.float() - ref).abs().max().item() < 2.5e-2
+
+
+def test_flash_attention_rescale_branch_with_spiked_keys():
+    """Force the running max to jump at a late tile (guide rule 26): one key row aligned with the queries."""
+    B, H, Nq, Nk = 1, 2, 64, 640
+    q = _rand((B, Nq, H, 64), 31, 0.3, torch.bfloat16)
+    k = _rand((B, Nk, H, 64), 32, 0.3, torch.bfloat16)
+    v = _rand((B, Nk, H, 64), 33, 1.0, torch.bfloat16)
+    k[:, 70] = q[:, 5] * 30.0       # tile 1
+    k[:, 333] = q[:, 5] * 90.0      # tile 5: max jumps again
+    k[:, 639] = q[:, 9] * 120.0     # last key of the last tile
+    o = ops.flash_attention(q, k, v)
+    ref = _attn_ref(q, k, v)
+    assert (o.float() - ref).abs().max().item() < 3e-2
+
+
+@pytest.mark.parametrize("D,eps,in_bf16", [(1024, 1e-6, False), (768, 1e-12, False), (128, 1e-12, True), (256, 1e-6, False)])
+def test_layernorm(D, eps, in_bf16):
+    rows = 1003
+    x = _rand((rows, D), 41, 3.0) + 0.7
+    if in_bf16:
+        x = x.to(torch.bfloat16)
+    add = _rand((rows, D), 42)
+    g, b = _rand((D,), 43) * 0.1 + 1.0, _rand((D,), 44) * 0.1
+    ob, of = ops.layernorm(x, g, b, eps, add=add, want_f32=True)
+    ref = torch.nn.functional.layer_norm(x.float() + add, (D,), g, b, eps)
+    assert (of - ref).abs().max().item() < 2e-5
+    assert _rel(ob.float(), ref) < 5e-3
+    ob2, _ = ops.layernorm(x, g, b, eps)
+    ref2 = torch.nn.functional.layer_norm(x.float(), (D,), g, b, eps)
+    assert _rel(ob2.float(), ref2) < 5e-3
+
+
+def test_layernorm_out_row_map():
+    B, S, nq, D = 3, 20, 8, 128
+    x = _rand((B * nq, D), 45)
+    g, b = torch.ones(D, device=DEV), torch.zeros(D, device=DEV)
+    of = torch.zeros((B, S, D), device=DEV)
+    obf = torch.zeros((B, S, D), device=DEV, dtype=torch.bfloat16)
+    ops.layernorm_raw(x.data_ptr(), True, None, g.data_ptr(), b.data_ptr(), obf.data_ptr(), of.data_ptr(), B * nq, D,
+                      1e-12, out_rows=(D, nq, S * D))
+    ref = torch.nn.functional.layer_norm(x, (D,), g, b, 1e-12).view(B, nq, D)
+    assert (of[:, :nq] - ref).abs().max().item() < 2e-5
+    assert of[:, nq:].abs().max().item() == 0.0
+
+
+def test_patchify_is_an_exact_gather():
+    B, T, H, W, P = 2, 3, 64, 48, 16
+    clip = _rand((B, T, 3, H, W), 51)
+    out = ops.patchify(clip, P)
+    ref = clip.view(B, T, 3, H // P, P, W // P, P).permute(0, 1, 3, 5, 2, 4, 6).reshape(-1, 3 * P * P)
+    assert torch.equal(out, ref.to(torch.bfloat16))
+
+
+def test_qformer_embed_ln():
+    B, nq, Lt, d, V = 3, 16, 7, 128, 1000
+    qt, we, pe = _rand((nq, d), 61, 0.02), _rand((V, d), 62, 0.02), _rand((64, d), 63, 0.02)
+    ids = torch.randint(0, V, (B, Lt), device=DEV)
+    g, b = _rand((d,), 64) * 0.1 + 1.0, _rand((d,), 65) * 0.1
+    of = torch.empty((B, nq + Lt, d), device=DEV)
+    ob = torch.empty((B, nq + Lt, d), device=DEV, dtype=torch.bfloat16)
+    ops.qformer_embed_ln(qt, we, pe, ids, g, b, 1e-12, of, ob)
+    emb = torch.cat([qt.expand(B, -1, -1), we[ids] + pe[:Lt]], dim=1)
+    ref = torch.nn.functional.layer_norm(emb, (d,), g, b, 1e-12)
+    assert (of - ref).abs().max().item() < 2e-5
+    assert _rel(ob.float(), ref) < 5e-3
+
+
+def test_cast_is_round_to_nearest_even():
+    x = _rand((1000003,), 71, 10.0)
+    assert torch.equal(ops.cast_bf16(x), x.to(torch.bfloat16))
