@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""Headline benchmark: encode_img clips/s (UMT-L/16 23 blocks + Q-Former + llama_proj, 16 frames @ 224).
+
+  python bench.py --gpus N --steps K --warmup W
+N > 1 is launched by the driver through torch.distributed.run, one rank per GPU.  A step is one
+`encode_img` over a batch of 32 synthetic clips already resident in HBM (BASELINE.json configs[1]);
+per-GPU work is fixed as N grows (weak scaling), clips are independent so there is no data-path
+collective; for N > 1 the step ends with the all_gather of the [32,96,4096] outputs.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from hawkeye_amd import dist as hdist  # noqa: E402
+from hawkeye_amd import posembed, weights as W  # noqa: E402
+from hawkeye_amd.config import FULL  # noqa: E402
+from hawkeye_amd.engine import flops_per_clip  # noqa: E402
+from hawkeye_amd.model import HawkEyeEncoder  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def cpu_baseline(sd, frames, lt, seed):
+    """The oracle (CPU fp32 restatement of the reference path) timed on this box's host cores,
+    one clip = a bounded sample of the same workload."""
+    from oracle import encode_img_oracle as O
+    cores = int(os.environ.get("OMP_NUM_THREADS", 0)) or min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    image = W.make_clip(1, frames, FULL.img_size, seed)
+    ids, mask = W.make_instruction_ids(1, lt, FULL.qf_vocab, seed)
+    table = posembed.video_pos_embed(frames, FULL.patches_per_frame, FULL.encoder_embed_dim, FULL.ckpt_num_frame)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        out, _ = O.encode_img(sd, FULL.to_dict(), image, ids, mask, table)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"1 clip, T={frames}, Lt={lt}, fp32 oracle (torch CPU, {cores} threads), {dt:.1f} s"}, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU per step")
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--lt", type=int, default=32, help="instruction tokens")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    args = ap.parse_args()
+
+    rank, local_rank, world = hdist.init("nccl")
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the encode_img path has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    cfg, seed = FULL, 1
+    B, T, Lt = args.batch, args.frames, args.lt
+    sd = W.make_state_dict(cfg, seed)
+    model = HawkEyeEncoder(cfg, out_dtype=torch.bfloat16)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    model.vision_encoder.encoder.pos_embed = posembed.video_pos_embed(
+        T, cfg.patches_per_frame, cfg.encoder_embed_dim, cfg.ckpt_num_frame)
+    # synthetic inputs resident in HBM before the timed region; different clips per rank
+    image = W.make_clip(B, T, cfg.img_size, seed + 100 * rank).to(dev)
+    ids, mask = W.make_instruction_ids(B, Lt, cfg.qf_vocab, seed)
+    ids, mask = ids.to(dev), mask.to(dev)
+    gather = world > 1 and not args.no_gather
+
+    def step():
+        out, _ = model.encode_img(image, (ids, mask))
+        if gather:
+            out = hdist.gather_outputs(out)
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    hdist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        out = step()
+    ev1.record()
+    hdist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    wall = hdist.max_over_ranks(wall, dev)
+
+    if rank == 0:
+        clips = world * B * args.steps
+        value = clips / wall
+        fl = flops_per_clip(cfg, T, Lt)
+        # roofline of the step (the whole launch sequence of one encode_img): algorithmic FLOPs of
+        # the B clips one step processes / the step's device time from HIP events on the launch stream
+        step_s = dev_ms / 1e3 / args.steps
+        achieved = fl * B / step_s / 1e12
+        res = {
+            "metric": "encode_img clips/s (UMT-L/16+QFormer,16f@224)", "value": round(value, 3), "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(wall / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"encode_img B={B}/GPU T={T} 224px Lt={Lt} (BASELINE configs[1])",
+                       "clips_per_gpu": B, "frames": T, "tokens_per_clip": T * cfg.patches_per_frame,
+                       "vit_blocks": cfg.run_depth, "parallelism": f"clip-sharded x{world}",
+                       "output_all_gather": bool(gather)},
+            "roofline": {"bound": "mfma", "kernel": "encode_img step (all launches of one call)",
+                         "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "gflop_per_clip": round(fl / 1e9, 1), "device_ms_per_step": round(step_s * 1e3, 3)},
+        }
+        if not args.no_cpu_baseline:
+            base, ref = cpu_baseline(sd, T, Lt, seed)
+            res["cpu_baseline"] = base
+            # the same clip through the HIP path, checked against the oracle run that was just timed
+            img1 = W.make_clip(1, T, cfg.img_size, seed).to(dev)
+            i1, m1 = W.make_instruction_ids(1, Lt, cfg.qf_vocab, seed)
+            model.out_dtype = torch.float32
+            got, _ = model.encode_img(img1, (i1.to(dev), m1.to(dev)))
+            a, b = got.double().flatten().cpu(), ref.double().flatten()
+            res["parity"] = {"cosine": round(float(a @ b / (a.norm() * b.norm())), 6),
+                             "max_rel_err": round(float((a - b).abs().max() / b.abs().max()), 5)}
+        print(json.dumps(res), flush=True)
+    hdist.barrier()
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

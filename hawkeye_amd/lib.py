@@ -7,6 +7,11 @@ missing, load() raises, and every op in hawkeye_amd.ops goes through load().
 import ctypes as C
 import os
 
+# torch first: PyTorch-ROCm ships its own libamdhip64.so.7 and must be the HIP runtime of the
+# process.  If this library were loaded before torch, its DT_NEEDED would pull /opt/rocm's copy
+# in first and the process would end up with a mixed runtime ("no ROCm-capable device").
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhawkeye_hip.so")
 
