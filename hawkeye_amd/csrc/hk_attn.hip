@@ -36,6 +36,7 @@ struct AttnParams {
 constexpr int QB = 128;   // query rows per workgroup
 constexpr int KT = 64;    // keys per tile
 constexpr float NEG_BIG = -1.0e30f;
+constexpr float RESCALE_THR = 8.0f;  // log2 units
 
 // v_permlane32_swap exchanges lanes 32-63 of its first operand with lanes 0-31 of its second:
 // called on two copies of x, one result holds (own, partner) and the other (partner, own).
@@ -59,7 +60,7 @@ __device__ __forceinline__ float half_swap_sum(float x) {
 }
 
 template <bool HAS_BIAS>
-__global__ __launch_bounds__(256) void hk_attn_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, HAS_BIAS ? 1 : 2) void hk_attn_kernel(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KT * 128];  // [stage][K|V][64 keys][128 B]
 
     const int tid = threadIdx.x;
@@ -102,13 +103,25 @@ __global__ __launch_bounds__(256) void hk_attn_kernel(const AttnParams p) {
         vst[i] = key * 128 + ((c ^ (((key >> 1) & 1) << 2)) << 4);
     }
     bf16x8 kr[2], vr[2];
+    const __bf16* kp = kbase + (int64_t)lkey * p.ldk;   // this thread's rows of the NEXT tile to load
+    const __bf16* vp_ = vbase + (int64_t)lkey * p.ldv;
+    const int64_t k32 = 32 * p.ldk, v32 = 32 * p.ldv;
     auto gload = [&](int tile) {
+        if ((tile + 1) * KT <= p.Nk) {
+            kr[0] = *reinterpret_cast<const bf16x8*>(kp);
+            kr[1] = *reinterpret_cast<const bf16x8*>(kp + k32);
+            vr[0] = *reinterpret_cast<const bf16x8*>(vp_);
+            vr[1] = *reinterpret_cast<const bf16x8*>(vp_ + v32);
+        } else {  // ragged last tile: clamp to the last key (masked to -inf below)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int key = min(tile * KT + i * 32 + lkey, p.Nk - 1);
-            kr[i] = *reinterpret_cast<const bf16x8*>(kbase + (int64_t)key * p.ldk);
-            vr[i] = *reinterpret_cast<const bf16x8*>(vbase + (int64_t)key * p.ldv);
+            for (int i = 0; i < 2; ++i) {
+                const int key = min(tile * KT + i * 32 + lkey, p.Nk - 1);
+                kr[i] = *reinterpret_cast<const bf16x8*>(kbase + (int64_t)key * p.ldk);
+                vr[i] = *reinterpret_cast<const bf16x8*>(vbase + (int64_t)key * p.ldv);
+            }
         }
+        kp += 2 * k32;
+        vp_ += 2 * v32;
     };
     auto lstore = [&](int stage) {
         char* ks = smem + stage * (2 * KT * 128);
@@ -142,7 +155,7 @@ __global__ __launch_bounds__(256) void hk_attn_kernel(const AttnParams p) {
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) ot[dt][i] = 0.f;
-    float m_run = NEG_BIG, l_run = 0.f;
+    float m_run = 0.f, l_run = 0.f;  // every stored quantity is relative to m_run
 
     const int NT = (p.Nk + KT - 1) / KT;
     gload(0);
@@ -155,12 +168,13 @@ __global__ __launch_bounds__(256) void hk_attn_kernel(const AttnParams p) {
         const char* ks = smem + cur * (2 * KT * 128);
         const char* vs = ks + KT * 128;
 
-        // ---- S^T = K . Q^T ----
+        // ---- S^T - m_run = K . Q^T - m_run: the running max enters as the initial accumulator ----
         f32x16 st[2];
+        const float negm = -m_run;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) st[kt][i] = 0.f;
+            for (int i = 0; i < 16; ++i) st[kt][i] = negm;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + kt * 32 * 128 + koff[s]);
@@ -189,29 +203,40 @@ __global__ __launch_bounds__(256) void hk_attn_kernel(const AttnParams p) {
         }
 
         // ---- online softmax (exp2 domain), row = lane column, both lane halves share a row ----
-        float mx = st[0][0];
+        // Deferred max: scores are kept relative to m_run, which moves only when some row of the
+        // wave outgrows it by more than RESCALE_THR (then P <= 2^THR, harmless in fp32/bf16).  The
+        // decision is taken before any P of this tile exists and after the previous tile's P.V
+        // is complete, so O, l and this tile's scores are the only things at the old scale.
+        float mx = fmaxf(st[0][0], st[0][1]);
 #pragma unroll
-        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, st[0][i]);
+        for (int i = 2; i < 16; i += 2) mx = fmaxf(mx, fmaxf(st[0][i], st[0][i + 1]));
 #pragma unroll
-        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, st[1][i]);
+        for (int i = 0; i < 16; i += 2) mx = fmaxf(mx, fmaxf(st[1][i], st[1][i + 1]));
         mx = half_swap_max(mx);
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
+        if (__builtin_amdgcn_ballot_w64(t == 0 || mx > RESCALE_THR) != 0) {
+            const float delta = t == 0 ? mx : fmaxf(mx, 0.f);
+            const float alpha = t == 0 ? 0.f : __builtin_amdgcn_exp2f(-delta);
+            m_run += delta;
+            l_run *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) ot[dt][i] *= alpha;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) st[kt][i] -= delta;
+        }
         float rs = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float e = __builtin_amdgcn_exp2f(st[kt][i] - m_new);
+                const float e = __builtin_amdgcn_exp2f(st[kt][i]);
                 st[kt][i] = e;
                 rs += e;
             }
-        l_run = l_run * alpha + rs;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) ot[dt][i] *= alpha;
+        l_run += rs;
 
         // ---- P^T fragments straight from the accumulator registers ----
         bf16x8 pf[4];
