@@ -17,6 +17,7 @@
 //
 // Pipeline: two LDS stages; the loads of K-tile t+1 are issued before the MFMAs of tile t and
 // retired by one vmcnt(0)+barrier per K-tile.
+#include <stdlib.h>
 #include "hk_common.h"
 
 namespace {
@@ -56,6 +57,217 @@ __device__ __forceinline__ float gelu_erf(float x) {
     p = fmaf(p, t, -1.6279250383377075f);
     const float h = 0.5f * __builtin_amdgcn_exp2f(p * t);  // 0.5 * erfc(|x|/sqrt2)
     return x * (x > 0.0f ? 1.0f - h : h);
+}
+
+
+// One lane's 4 consecutive output columns of one row: bias, column scale, activation, residual, store.
+__device__ __forceinline__ void epi_store(const GemmParams& p, f32x4 v, const f32x4 bias, int n, int64_t coff,
+                                          int64_t roff) {
+    v += bias;
+    if (n < p.scale_cols) v *= p.scale;
+    if (p.act == HK_ACT_GELU_ERF) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+    }
+    if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + roff + n);
+    if (p.out_f32) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + coff + n) = v;
+    } else {
+        u32x2 o;
+        o[0] = pack_bf16x2(v[0], v[1]);
+        o[1] = pack_bf16x2(v[2], v[3]);
+        *reinterpret_cast<u32x2*>(reinterpret_cast<__bf16*>(p.C) + coff + n) = o;
+    }
+}
+
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
+// ---------------------------------------------------------------------------------------------
+// 256x256x64 "ping-pong" kernel: 8 waves as 2 (M) x 4 (N); the two M-groups of waves run one
+// barrier apart, so on every SIMD one wave is inside a 16-MFMA cluster while its partner reads
+// LDS fragments and issues LDS-DMA for the tiles ahead.
+//
+// LDS: 2 K-tile buffers x {A rows 0-127, A rows 128-255, W rows 0-127, W rows 128-255} x [128][64] bf16.
+// Per K-tile a wave runs 4 phases, one 64x32 output quadrant each:
+//     phase      reads (ds_read_b128)            stages (2 LDS-DMA per thread)       MFMA
+//     1          A rows 0-63 (8), W cols 0-31 (4)   A-half1 of tile t+1                 q(0,0)
+//     2          W cols 32-63 (4)                   W-half0 of tile t+1                 q(0,1)
+//     3          A rows 64-127 (8)                  W-half1 of tile t+1                 q(1,1)
+//     4          W cols 0-31 (4)                    A-half0 of tile t+2, vmcnt(2)       q(1,0)
+// Each phase is  {reads, stage} s_barrier {lgkmcnt(0), 16 MFMA} s_barrier.  With B(k) the k-th
+// barrier instance, group 0 runs phase p of tile t between B(8t+2p-2) and B(8t+2p), group 1 one
+// instance later.  Hazards (interval i = between B(i) and B(i+1); a read issued in interval i has
+// completed before its wave arrives at B(i+2)):
+//   WAR  a slot of buffer t&1 is restaged for tile t+2 only after every read of tile t from it:
+//        A-half0: last read group 0 phase 3 (interval 8t+4) -> staged from interval 8t+6 (phase 4) on;
+//        A-half1: last read group 1 phase 3 (8t+5)          -> staged from 8t+8 (phase 1 of t+1) on;
+//        W-halves: last read group 1 phase 4 (8t+7)         -> staged from 8t+10 (phases 2,3 of t+1) on.
+//   RAW  every wave retires all LDS-DMA of tile t+1 with the vmcnt(2) of its phase 4 of tile t
+//        (the 2 left in flight are A-half0 of t+2) and then arrives at a barrier (group 1: B(8t+8))
+//        that every reader of tile t+1 (first: group 0 in interval 8t+8) has to pass first.
+// Loads therefore stay in flight across 6-20 barriers and vmcnt never drains to 0 in the loop.
+// ---------------------------------------------------------------------------------------------
+#define HK_BAR() __builtin_amdgcn_s_barrier()
+
+__global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
+    constexpr int BK = 64;
+    constexpr int HALF = 128 * BK;  // elements in one half-tile (16 KB)
+    constexpr int BUF = 4 * HALF;   // A-h0, A-h1, W-h0, W-h1
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __bf16* lds = reinterpret_cast<__bf16*>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const int lid = xcd_remap(blockIdx.x, p.nbm * p.nbn);
+    const int m0 = (lid / p.nbn) * 256;
+    const int n0 = (lid % p.nbn) * 256;
+
+    // ---- loader: one LDS-DMA wave-instruction = 8 rows x 128 B; a half-tile = 2 per thread ----
+    const int lrow = lane >> 3, lpc = lane & 7;
+    const __bf16* gp[4][2];  // [slot kind][round]
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (i * 8 + wave) * 8 + lrow;
+            const int sw = (lpc ^ ((row >> 1) & 7)) << 3;
+            const int m = min(m0 + hf * 128 + row, p.M - 1);
+            const int n = min(n0 + hf * 128 + row, p.N - 1);
+            gp[hf][i] = p.A + p.a.off(m) + sw;
+            gp[2 + hf][i] = p.W + (int64_t)n * p.ldw + sw;
+        }
+    auto stage = [&](int kind, int tile) {
+        __bf16* dst = lds + (tile & 1) * BUF + kind * HALF + wave * 8 * BK;
+        glds16(gp[kind][0] + tile * BK, dst);
+        glds16(gp[kind][1] + tile * BK, dst + 64 * BK);
+    };
+
+    // ---- fragment offsets (elements): row (lane & 15), logical chunk kk*4 + (lane >> 4) ----
+    const int sw = (lane >> 1) & 7;
+    const int foff0 = (lane & 15) * BK + ((((lane >> 4)) ^ sw) << 3);
+    const int foff1 = (lane & 15) * BK + (((4 + (lane >> 4)) ^ sw) << 3);
+    const int a_base = wm * HALF;                                        // + mh*64*BK
+    const int w_base = (2 + (wn >> 1)) * HALF + (wn & 1) * 64 * BK;      // + nh*32*BK
+
+    f32x4 acc[2][2][4][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 xa[2][4], wb[2][2];
+
+    auto load_a = [&](int buf, int mh) {
+        const __bf16* s0 = lds + buf * BUF + a_base + mh * 64 * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            xa[0][i] = *reinterpret_cast<const bf16x8*>(s0 + i * 16 * BK + foff0);
+            xa[1][i] = *reinterpret_cast<const bf16x8*>(s0 + i * 16 * BK + foff1);
+        }
+    };
+    auto load_w = [&](int buf, int nh) {
+        const __bf16* s0 = lds + buf * BUF + w_base + nh * 32 * BK;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            wb[0][j] = *reinterpret_cast<const bf16x8*>(s0 + j * 16 * BK + foff0);
+            wb[1][j] = *reinterpret_cast<const bf16x8*>(s0 + j * 16 * BK + foff1);
+        }
+    };
+#define HK_MMA(MH, NH)                                                                                      \
+    do {                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        HK_BAR();                                                                                           \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        __builtin_amdgcn_s_setprio(1);                                                                      \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int i = 0; i < 4; ++i)      \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[MH][NH][i][j] =                               \
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[kk][j], xa[kk][i], acc[MH][NH][i][j], 0, 0, 0);  \
+        __builtin_amdgcn_s_setprio(0);                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        HK_BAR();                                                                                           \
+    } while (0)
+
+    const int KT = p.K / BK;
+    // prologue: tile 0 complete, A-half0 of tile 1 in flight
+    stage(0, 0);
+    stage(1, 0);
+    stage(2, 0);
+    stage(3, 0);
+    if (KT > 1) {
+        stage(0, 1);
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    HK_BAR();
+    if (wm == 1) HK_BAR();  // stagger group 1 by one barrier
+
+    for (int t = 0; t < KT; ++t) {
+        const int buf = t & 1;
+        const bool n1 = t + 1 < KT;
+        // phase 1
+        load_a(buf, 0);
+        load_w(buf, 0);
+        if (n1) stage(1, t + 1);
+        HK_MMA(0, 0);
+        // phase 2
+        load_w(buf, 1);
+        if (n1) stage(2, t + 1);
+        HK_MMA(0, 1);
+        // phase 3
+        load_a(buf, 1);
+        if (n1) stage(3, t + 1);
+        HK_MMA(1, 1);
+        // phase 4
+        load_w(buf, 0);
+        if (t + 2 < KT) {
+            stage(0, t + 2);
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        HK_MMA(1, 0);
+    }
+    if (wm == 0) HK_BAR();  // equalise the barrier count of the two groups
+#undef HK_MMA
+
+    // ---- epilogue ----
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+        f32x4 bias[2];
+        const int ncol = n0 + wn * 64 + nh * 32 + (lane >> 4) * 4;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = ncol + j * 16;
+            bias[j] = (p.bias != nullptr && n < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + n)
+                                                     : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + wm * 128 + mh * 64 + i * 16 + (lane & 15);
+                if (m >= p.M) continue;
+                const int64_t coff = p.c.off(m);
+                const int64_t roff = p.res ? p.r.off(m) : 0;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int n = ncol + j * 16;
+                    if (n < p.N) epi_store(p, acc[mh][nh][i][j], bias[j], n, coff, roff);
+                }
+            }
+    }
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -212,6 +424,26 @@ int launch(const GemmParams& p, hipStream_t stream) {
     return HK_OK;
 }
 
+int launch_pp(const GemmParams& p, hipStream_t stream) {
+    constexpr int LDS = 2 * 4 * 128 * 64 * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hk_gemm_pp_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) {
+            hk_set_error("hk_gemm_bf16: hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e));
+            return HK_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    GemmParams q = p;
+    q.nbm = (p.M + 255) / 256;
+    q.nbn = (p.N + 255) / 256;
+    hipLaunchKernelGGL(hk_gemm_pp_kernel, dim3(q.nbm * q.nbn), dim3(512), LDS, stream, q);
+    HK_CHECK_LAUNCH("hk_gemm_bf16");
+    return HK_OK;
+}
+
 }  // namespace
 
 extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
@@ -255,6 +487,7 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
 
     // Big tiles once they fill the chip; 128x128 (2 workgroups per CU) for the small Q-Former GEMMs.
     const long tiles256 = (long)((d->M + 255) / 256) * ((d->N + 255) / 256);
-    if (tiles256 >= 256 && d->N % 256 == 0) return launch<256, 256, 2, 4>(p, s);
+    static const int variant = getenv("HK_GEMM_VARIANT") ? atoi(getenv("HK_GEMM_VARIANT")) : 1;
+    if (tiles256 >= 256 && d->N % 256 == 0) return variant == 0 ? launch<256, 256, 2, 4>(p, s) : launch_pp(p, s);
     return launch<128, 128, 2, 2>(p, s);
 }

@@ -27,7 +27,8 @@ def _rel(a, ref):
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 1024), (300, 272, 128), (1, 16, 64),
-                                   (100352 // 8, 1024, 1024), (65600, 512, 256), (3136 * 2, 3072, 1024)])
+                                   (100352 // 8, 1024, 1024), (65600, 512, 256), (3136 * 2, 3072, 1024),
+                                   (66000, 256, 64), (66000, 256, 128), (65537, 512, 192), (16640, 4096, 320)])
 def test_gemm_plain_bf16_out(M, N, K):
     x = _rand((M, K), 1, dtype=torch.bfloat16)
     w = _rand((N, K), 2, 0.05, dtype=torch.bfloat16)
