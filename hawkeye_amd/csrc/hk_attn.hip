@@ -18,6 +18,8 @@
 // LDS images (128-byte rows = one key's 64 head dims), 16-byte chunk c of key row r stored at
 //     K: chunk c ^ ((r >> 1) & 7)        -> conflict-free ds_read_b128 of 32 rows x one chunk
 //     V: chunk c ^ (((r >> 1) & 1) << 2) -> conflict-free ds_read_b64_tr_b16 of 4 keys x 32 dims
+#include <stdlib.h>
+#include <type_traits>
 #include "hk_common.h"
 
 namespace {
@@ -36,7 +38,7 @@ struct AttnParams {
 constexpr int QB = 128;   // query rows per workgroup
 constexpr int KT = 64;    // keys per tile
 constexpr float NEG_BIG = -1.0e30f;
-constexpr float RESCALE_THR = 8.0f;  // log2 units
+constexpr float OVERFLOW_SUM = 1048576.0f;  // 2^20: a lane's 32-score partial row sum beyond this redoes the tile
 
 // v_permlane32_swap exchanges lanes 32-63 of its first operand with lanes 0-31 of its second:
 // called on two copies of x, one result holds (own, partner) and the other (partner, own).
@@ -59,8 +61,8 @@ __device__ __forceinline__ float half_swap_sum(float x) {
     return a + b;
 }
 
-template <bool HAS_BIAS>
-__global__ __launch_bounds__(256, HAS_BIAS ? 1 : 2) void hk_attn_kernel(const AttnParams p) {
+template <bool HAS_BIAS, int MODE, int OCC, int LOADER>
+__global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KT * 128];  // [stage][K|V][64 keys][128 B]
 
     const int tid = threadIdx.x;
@@ -132,6 +134,31 @@ __global__ __launch_bounds__(256, HAS_BIAS ? 1 : 2) void hk_attn_kernel(const At
             *reinterpret_cast<bf16x8*>(vs + vst[i]) = vr[i];
         }
     };
+    // LOADER 1: LDS-DMA (global_load_lds_dwordx4) instead of register staging.  The LDS image is
+    // lane-linear per wave-instruction (8 keys x 128 B), so the swizzles go on the SOURCE chunk.
+    const int ck = (tid & 7) ^ ((lkey >> 1) & 7);
+    const int cv = (tid & 7) ^ (((lkey >> 1) & 1) << 2);
+    const __bf16* kd = p.K + (int64_t)b * p.bsk + head * 64 + ck * 8 + (int64_t)lkey * p.ldk;
+    const __bf16* vd = p.V + (int64_t)b * p.bsv + head * 64 + cv * 8 + (int64_t)lkey * p.ldv;
+    auto gdma = [&](int tile) {
+        char* ks = smem + (tile & 1) * (2 * KT * 128) + wave * 8 * 128;
+        char* vs = ks + KT * 128;
+        if ((tile + 1) * KT <= p.Nk) {
+            glds16(kd, ks);
+            glds16(kd + k32, ks + 32 * 128);
+            glds16(vd, vs);
+            glds16(vd + v32, vs + 32 * 128);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int key = min(tile * KT + i * 32 + lkey, p.Nk - 1);
+                glds16(p.K + (int64_t)b * p.bsk + head * 64 + ck * 8 + (int64_t)key * p.ldk, ks + i * 32 * 128);
+                glds16(p.V + (int64_t)b * p.bsv + head * 64 + cv * 8 + (int64_t)key * p.ldv, vs + i * 32 * 128);
+            }
+        }
+        kd += 2 * k32;
+        vd += 2 * v32;
+    };
 
     // ---- per-lane LDS read offsets ----
     // K fragment (kt, ks): row 32 kt + r, logical chunk 2 ks + h
@@ -158,64 +185,84 @@ __global__ __launch_bounds__(256, HAS_BIAS ? 1 : 2) void hk_attn_kernel(const At
     float m_run = 0.f, l_run = 0.f;  // every stored quantity is relative to m_run
 
     const int NT = (p.Nk + KT - 1) / KT;
-    gload(0);
-    lstore(0);
+    if (LOADER == 1) {
+        gdma(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        gload(0);
+        lstore(0);
+    }
     __syncthreads();
 
-    for (int t = 0; t < NT; ++t) {
+    // One K/V tile.  FIRST (tile 0) and RAGGED (last tile when Nk % 64 != 0) are compile-time so the
+    // steady-state body carries neither the key mask nor the first-tile special case.
+    //
+    // Scores are kept relative to m_run, which enters as the initial MFMA accumulator.
+    // MODE 0: the row maximum of every tile is taken and m_run moves when some row of the wave
+    //   outgrows it by more than 8 bits (deferred rescale).
+    // MODE 1: the common path is exp2 + row sum only.  m_run is set from the true row maximum on the
+    //   first tile and afterwards only when a tile "overflows" -- some lane's partial row sum leaves
+    //   [0, OVERFLOW_SUM], i.e. a score exceeded m_run by ~20 bits or exp2 returned inf; that tile is
+    //   redone with the maximum taken.
+    // Either way the decision is wave-uniform, is taken after the previous tile's P.V is complete and
+    // before any P of this tile is used, so O, l and this tile's scores are the only things at the
+    // old scale when a rescale happens.
+    auto tile = [&](const int t, auto first_c, auto ragged_c) {
+        constexpr bool FIRST = decltype(first_c)::value;
+        constexpr bool RAGGED = decltype(ragged_c)::value;
         const int cur = t & 1;
-        if (t + 1 < NT) gload(t + 1);
+        if (t + 1 < NT) {
+            if (LOADER == 1) gdma(t + 1); else gload(t + 1);
+        }
         const char* ks = smem + cur * (2 * KT * 128);
         const char* vs = ks + KT * 128;
-
-        // ---- S^T - m_run = K . Q^T - m_run: the running max enters as the initial accumulator ----
         f32x16 st[2];
-        const float negm = -m_run;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) st[kt][i] = negm;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + kt * 32 * 128 + koff[s]);
-                st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[kt], 0, 0, 0);
-            }
-        }
-        // register i of st[kt] <-> key t*64 + 32 kt + (i & 3) + 8 (i >> 2) + 4 h
-        if (HAS_BIAS) {
-            const float* kb = p.key_bias + (int64_t)b * p.Nk;
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int key = t * KT + 32 * kt + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (key < p.Nk) st[kt][i] += kb[key] * HK_LOG2E;
-                }
-        }
-        if ((t + 1) * KT > p.Nk) {  // ragged last tile: keys >= Nk do not exist
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int key = t * KT + 32 * kt + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (key >= p.Nk) st[kt][i] = NEG_BIG;
-                }
-        }
+        float rs;
 
-        // ---- online softmax (exp2 domain), row = lane column, both lane halves share a row ----
-        // Deferred max: scores are kept relative to m_run, which moves only when some row of the
-        // wave outgrows it by more than RESCALE_THR (then P <= 2^THR, harmless in fp32/bf16).  The
-        // decision is taken before any P of this tile exists and after the previous tile's P.V
-        // is complete, so O, l and this tile's scores are the only things at the old scale.
-        float mx = fmaxf(st[0][0], st[0][1]);
+        auto scores = [&]() {
+            const float negm = -m_run;
 #pragma unroll
-        for (int i = 2; i < 16; i += 2) mx = fmaxf(mx, fmaxf(st[0][i], st[0][i + 1]));
+            for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
-        for (int i = 0; i < 16; i += 2) mx = fmaxf(mx, fmaxf(st[1][i], st[1][i + 1]));
-        mx = half_swap_max(mx);
-        if (__builtin_amdgcn_ballot_w64(t == 0 || mx > RESCALE_THR) != 0) {
-            const float delta = t == 0 ? mx : fmaxf(mx, 0.f);
-            const float alpha = t == 0 ? 0.f : __builtin_amdgcn_exp2f(-delta);
+                for (int i = 0; i < 16; ++i) st[kt][i] = negm;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + kt * 32 * 128 + koff[s]);
+                    st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[kt], 0, 0, 0);
+                }
+            }
+            // register i of st[kt] <-> key t*64 + 32 kt + (i & 3) + 8 (i >> 2) + 4 h
+            if (HAS_BIAS) {
+                const float* kb = p.key_bias + (int64_t)b * p.Nk;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int key = t * KT + 32 * kt + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        if (key < p.Nk) st[kt][i] += kb[key] * HK_LOG2E;
+                    }
+            }
+            if (RAGGED) {  // keys >= Nk do not exist
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int key = t * KT + 32 * kt + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        if (key >= p.Nk) st[kt][i] = NEG_BIG;
+                    }
+            }
+        };
+        auto rowmax = [&]() {
+            float mx = fmaxf(st[0][0], st[0][1]);
+#pragma unroll
+            for (int i = 2; i < 16; i += 2) mx = fmaxf(mx, fmaxf(st[0][i], st[0][i + 1]));
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) mx = fmaxf(mx, fmaxf(st[1][i], st[1][i + 1]));
+            return half_swap_max(mx);
+        };
+        auto move_max = [&](const float mx) {  // m_run += delta; everything at the old scale follows
+            const float delta = FIRST ? mx : fmaxf(mx, 0.f);
+            const float alpha = FIRST ? 0.f : __builtin_amdgcn_exp2f(-delta);
             m_run += delta;
             l_run *= alpha;
 #pragma unroll
@@ -226,16 +273,35 @@ __global__ __launch_bounds__(256, HAS_BIAS ? 1 : 2) void hk_attn_kernel(const At
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) st[kt][i] -= delta;
-        }
-        float rs = 0.f;
+        };
+        auto exp_sum = [&]() {
+            rs = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float e = __builtin_amdgcn_exp2f(st[kt][i]);
-                st[kt][i] = e;
-                rs += e;
+                for (int i = 0; i < 16; ++i) {
+                    const float e = __builtin_amdgcn_exp2f(st[kt][i]);
+                    st[kt][i] = e;
+                    rs += e;
+                }
+        };
+
+        scores();
+        if (FIRST) {
+            move_max(rowmax());
+            exp_sum();
+        } else if (MODE == 0) {
+            const float mx = rowmax();
+            if (__builtin_amdgcn_ballot_w64(mx > 8.0f) != 0) move_max(mx);
+            exp_sum();
+        } else {
+            exp_sum();
+            if (__builtin_amdgcn_ballot_w64(!(rs <= OVERFLOW_SUM)) != 0) {
+                scores();
+                move_max(rowmax());
+                exp_sum();
             }
+        }
         l_run += rs;
 
         // ---- P^T fragments straight from the accumulator registers ----
@@ -269,8 +335,23 @@ __global__ __launch_bounds__(256, HAS_BIAS ? 1 : 2) void hk_attn_kernel(const At
             }
         }
 
-        if (t + 1 < NT) lstore(cur ^ 1);
+        if (LOADER == 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (t + 1 < NT) {
+            lstore(cur ^ 1);
+        }
         __syncthreads();
+    };
+
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    const bool ragged = (p.Nk % KT) != 0;
+    if (NT == 1) {
+        if (ragged) tile(0, T_{}, T_{}); else tile(0, T_{}, F_{});
+    } else {
+        tile(0, T_{}, F_{});
+        for (int t = 1; t < NT - 1; ++t) tile(t, F_{}, F_{});
+        if (ragged) tile(NT - 1, F_{}, T_{}); else tile(NT - 1, F_{}, F_{});
     }
 
     // ---- normalise and store: lane (r, h) holds O[q0 + r][32 dt + 8 g + 4 h .. +4] ----
@@ -324,10 +405,22 @@ extern "C" int hk_flash_attn_bf16(const hk_attn_desc* d, void* stream) {
     const long nwg = (long)p.nqb * d->H * d->B;
     HK_REQUIRE(nwg < (1L << 31), "hk_flash_attn_bf16: grid too large");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (d->key_bias)
-        hipLaunchKernelGGL(hk_attn_kernel<true>, dim3((unsigned)nwg), dim3(256), 0, s, p);
-    else
-        hipLaunchKernelGGL(hk_attn_kernel<false>, dim3((unsigned)nwg), dim3(256), 0, s, p);
+    // HK_ATTN_MODE: softmax variant; HK_ATTN_OCC: waves per SIMD the register allocation targets;
+    // HK_ATTN_LOADER: 0 register-staged K/V tiles, 1 LDS-DMA (see the kernel).
+    static const int mode = getenv("HK_ATTN_MODE") ? atoi(getenv("HK_ATTN_MODE")) : 1;
+    static const int occ = getenv("HK_ATTN_OCC") ? atoi(getenv("HK_ATTN_OCC")) : 3;
+    static const int ldr = getenv("HK_ATTN_LOADER") ? atoi(getenv("HK_ATTN_LOADER")) : 1;
+    const dim3 grid((unsigned)nwg), block(256);
+#define HK_ATTN_LAUNCH(BIAS, M, O, L) hipLaunchKernelGGL((hk_attn_kernel<BIAS, M, O, L>), grid, block, 0, s, p)
+    if (d->key_bias) HK_ATTN_LAUNCH(true, 0, 1, 0);
+    else if (ldr == 1 && mode == 1 && occ == 3) HK_ATTN_LAUNCH(false, 1, 3, 1);
+    else if (ldr == 1 && mode == 1) HK_ATTN_LAUNCH(false, 1, 2, 1);
+    else if (ldr == 1 && occ == 3) HK_ATTN_LAUNCH(false, 0, 3, 1);
+    else if (mode == 1 && occ == 3) HK_ATTN_LAUNCH(false, 1, 3, 0);
+    else if (mode == 1) HK_ATTN_LAUNCH(false, 1, 2, 0);
+    else if (occ == 3) HK_ATTN_LAUNCH(false, 0, 3, 0);
+    else HK_ATTN_LAUNCH(false, 0, 2, 0);
+#undef HK_ATTN_LAUNCH
     HK_CHECK_LAUNCH("hk_flash_attn_bf16");
     return HK_OK;
 }
