@@ -35,12 +35,13 @@ struct GemmParams {
     const __bf16* A;
     const __bf16* W;
     const float* bias;
-    const float* res;
+    const void* res;
     void* C;
     int M, N, K;
     RowMap a, c, r;
     int64_t ldw;
-    int act, out_f32, scale_cols;
+    int act, out_f32, res_bf16, scale_cols, dbg, gm;
+    unsigned long long* trace;  // debug: per workgroup [hwid, t_start, then (t_loop_end, t_epi_end) per tile]
     float scale;
     int nbm, nbn;
 };
@@ -60,6 +61,15 @@ __device__ __forceinline__ float gelu_erf(float x) {
 }
 
 
+// 4 consecutive residual elements (fp32 or bf16) at element offset `off`
+__device__ __forceinline__ f32x4 load_res4(const GemmParams& p, int64_t off) {
+    if (p.res_bf16) {
+        const u32x2 w = *reinterpret_cast<const u32x2*>(reinterpret_cast<const __bf16*>(p.res) + off);
+        return f32x4{bf16_lo(w[0]), bf16_hi(w[0]), bf16_lo(w[1]), bf16_hi(w[1])};
+    }
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + off);
+}
+
 // One lane's 4 consecutive output columns of one row: bias, column scale, activation, residual, store.
 __device__ __forceinline__ void epi_store(const GemmParams& p, f32x4 v, const f32x4 bias, int n, int64_t coff,
                                           int64_t roff) {
@@ -69,7 +79,7 @@ __device__ __forceinline__ void epi_store(const GemmParams& p, f32x4 v, const f3
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
     }
-    if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + roff + n);
+    if (p.res) v += load_res4(p, roff + n);
     if (p.out_f32) {
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + coff + n) = v;
     } else {
@@ -78,6 +88,17 @@ __device__ __forceinline__ void epi_store(const GemmParams& p, f32x4 v, const f3
         o[1] = pack_bf16x2(v[2], v[3]);
         *reinterpret_cast<u32x2*>(reinterpret_cast<__bf16*>(p.C) + coff + n) = o;
     }
+}
+
+// Tile raster: groups of GM m-panels, inside a group m fastest, so any run of 32 consecutive tile ids
+// (what the 32 CUs of one XCD work on at a time) is a compact GM x (32 / GM) patch: each A panel and each
+// W panel it touches is shared by several concurrent tiles in that XCD's L2.
+__device__ __forceinline__ void tile_coords(int lid, int nbm, int nbn, int gm_, int& tm, int& tn) {
+    const int per = gm_ * nbn;
+    const int g = lid / per, r = lid - g * per;
+    const int gm = min(gm_, nbm - g * gm_);
+    tn = r / gm;
+    tm = g * gm_ + (r - tn * gm);
 }
 
 __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
@@ -112,6 +133,16 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
 // ---------------------------------------------------------------------------------------------
 #define HK_BAR() __builtin_amdgcn_s_barrier()
 
+// Persistent form: one workgroup per CU walks a list of output tiles and treats (tile, K-tile) as ONE
+// stream of K-tiles, so the staging pipeline above never drains at a tile boundary: while a tile's
+// last K-tiles are multiplied the next tile's first K-tiles are already landing, the epilogue's
+// stores are fire-and-forget, and there is no workgroup launch / prologue latency / store-ack wait
+// per tile (measured 6-7 us of a 30-40 us tile at K = 1024 in the one-tile-per-workgroup form).
+// The epilogue transposes each wave's 128x64 sub-tile through a private 4 KB LDS region above the
+// operand buffers (128 KB + 8 x 4 KB = all 160 KB of the CU) and writes whole row segments.
+// EPI selects the one epilogue this instantiation carries: 0 = bf16 out, no residual; 1 = fp32 staging
+// (fp32 out and/or fp32 residual); 2 = bf16 residual stream updated in place.
+template <int EPI>
 __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
     constexpr int BK = 64;
     constexpr int HALF = 128 * BK;  // elements in one half-tile (16 KB)
@@ -125,29 +156,60 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
 
-    const int lid = xcd_remap(blockIdx.x, p.nbm * p.nbn);
-    const int m0 = (lid / p.nbn) * 256;
-    const int n0 = (lid % p.nbn) * 256;
+    // ---- this workgroup's tile list: the workgroups that share an XCD (blockIdx % 8) split one
+    // contiguous run of tiles (n fastest) round-robin, so concurrent tiles share A panels in that L2 ----
+    const int nwg = p.nbm * p.nbn;
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int nbx = ((int)gridDim.x - xcd + 7) >> 3;  // workgroups on this XCD
+    const int q8 = nwg >> 3, r8 = nwg & 7;
+    const int c0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int cnt = q8 + (xcd < r8 ? 1 : 0);
+    const int ntile = jb < cnt ? (cnt - jb + nbx - 1) / nbx : 0;
+    const int KT = (p.dbg & 2) ? 1 : p.K / BK;  // dbg 2: timing-only build, one K-tile per tile
+    if (ntile == 0) return;                      // uniform per workgroup
 
-    // ---- loader: one LDS-DMA wave-instruction = 8 rows x 128 B; a half-tile = 2 per thread ----
+    // ---- loader: one LDS-DMA wave-instruction = 8 rows x 128 B; a half-tile = 2 per thread.
+    // Each slot kind (A-h0, A-h1, W-h0, W-h1) has its own cursor into the K-tile stream. ----
     const int lrow = lane >> 3, lpc = lane & 7;
-    const __bf16* gp[4][2];  // [slot kind][round]
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
+    const __bf16* gp[4][2];  // [slot kind][round]: row base of the tile being staged
+    int s_tile[4], s_k[4], s_par[4];
+    auto set_ptrs = [&](int kind) {
+        const int lid = c0 + jb + s_tile[kind] * nbx;
+        int tm, tn;
+        tile_coords(lid, p.nbm, p.nbn, p.gm, tm, tn);
+        const int t0 = (kind < 2 ? tm : tn) * 256;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = (i * 8 + wave) * 8 + lrow;
             const int sw = (lpc ^ ((row >> 1) & 7)) << 3;
-            const int m = min(m0 + hf * 128 + row, p.M - 1);
-            const int n = min(n0 + hf * 128 + row, p.N - 1);
-            gp[hf][i] = p.A + p.a.off(m) + sw;
-            gp[2 + hf][i] = p.W + (int64_t)n * p.ldw + sw;
+            if (kind < 2) {
+                const int m = min(t0 + kind * 128 + row, p.M - 1);
+                gp[kind][i] = p.A + p.a.off(m) + sw;
+            } else {
+                const int n = min(t0 + (kind - 2) * 128 + row, p.N - 1);
+                gp[kind][i] = p.W + (int64_t)n * p.ldw + sw;
+            }
         }
-    auto stage = [&](int kind, int tile) {
-        __bf16* dst = lds + (tile & 1) * BUF + kind * HALF + wave * 8 * BK;
-        glds16(gp[kind][0] + tile * BK, dst);
-        glds16(gp[kind][1] + tile * BK, dst + 64 * BK);
     };
+    auto stage = [&](int kind) -> bool {  // stage the cursor's half-tile, advance the cursor
+        if (s_tile[kind] >= ntile) return false;
+        __bf16* dst = lds + s_par[kind] * BUF + kind * HALF + wave * 8 * BK;
+        glds16(gp[kind][0] + s_k[kind] * BK, dst);
+        glds16(gp[kind][1] + s_k[kind] * BK, dst + 64 * BK);
+        s_par[kind] ^= 1;
+        if (++s_k[kind] == KT) {
+            s_k[kind] = 0;
+            if (++s_tile[kind] < ntile) set_ptrs(kind);
+        }
+        return true;
+    };
+#pragma unroll
+    for (int kind = 0; kind < 4; ++kind) {
+        s_tile[kind] = 0;
+        s_k[kind] = 0;
+        s_par[kind] = 0;
+        set_ptrs(kind);
+    }
 
     // ---- fragment offsets (elements): row (lane & 15), logical chunk kk*4 + (lane >> 4) ----
     const int sw = (lane >> 1) & 7;
@@ -157,15 +219,18 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
     const int w_base = (2 + (wn >> 1)) * HALF + (wn & 1) * 64 * BK;      // + nh*32*BK
 
     f32x4 acc[2][2][4][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 xa[2][4], wb[2][2];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    zero_acc();
 
     auto load_a = [&](int buf, int mh) {
         const __bf16* s0 = lds + buf * BUF + a_base + mh * 64 * BK;
@@ -198,14 +263,176 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
         HK_BAR();                                                                                           \
     } while (0)
 
-    const int KT = p.K / BK;
-    // prologue: tile 0 complete, A-half0 of tile 1 in flight
-    stage(0, 0);
-    stage(1, 0);
-    stage(2, 0);
-    stage(3, 0);
-    if (KT > 1) {
-        stage(0, 1);
+    // ---- epilogue of one tile (no workgroup barrier inside; LDS region private to the wave) ----
+    // The accumulator layout (lane = 1 row x 4 columns of a 16x16 tile) would store 32-byte pieces of
+    // 16 rows per instruction; instead 16 (fp32) / 32 (bf16) rows at a time go through LDS, XOR-swizzled,
+    // and leave as whole 256 / 128-byte row segments, 16 bytes per lane.  The fp32 residual is read the
+    // same way.  Bias, column scale and GELU are applied on the accumulator layout, before LDS.
+    char* stg = smem + 2 * BUF * 2 + wave * 4096;
+    auto epilogue = [&](int m0, int n0) {
+        if (p.dbg & 1) {  // dbg 1: timing-only build, no epilogue (accumulators kept live)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[a][b][i][j]));
+            return;
+        }
+        f32x4 bias[2][2];
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 64 + nh * 32 + j * 16 + (lane >> 4) * 4;
+                bias[nh][j] = (p.bias != nullptr && n < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + n)
+                                                             : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        auto pre = [&](f32x4 v, int nh, int j) {
+            const int n = n0 + wn * 64 + nh * 32 + j * 16 + (lane >> 4) * 4;
+            v += bias[nh][j];
+            if (n < p.scale_cols) v *= p.scale;
+            if (p.act == HK_ACT_GELU_ERF) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            }
+            return v;
+        };
+        const int mw = m0 + wm * 128;  // first row / column of this wave's sub-tile
+        const int nw = n0 + wn * 64;
+        const int r16 = lane & 15, g4 = lane >> 4;
+        if (EPI == 0) {
+            // bf16 out, no residual: 32 rows x 128 B per round; 16-B chunk c of row r lives at chunk c ^ (r & 7)
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                for (int i2 = 0; i2 < 2; ++i2) {
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const f32x4 v = pre(acc[mh][nh][i2 * 2 + ii][j], nh, j);
+                                u32x2 o;
+                                o[0] = pack_bf16x2(v[0], v[1]);
+                                o[1] = pack_bf16x2(v[2], v[3]);
+                                const int row = ii * 16 + r16;
+                                const int ch = nh * 4 + j * 2 + (g4 >> 1);
+                                *reinterpret_cast<u32x2*>(stg + row * 128 + ((ch ^ (row & 7)) << 4) + (g4 & 1) * 8) = o;
+                            }
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int row = it * 8 + (lane >> 3), ch = lane & 7;
+                        const u32x4 o = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((ch ^ (row & 7)) << 4));
+                        const int m = mw + mh * 64 + i2 * 32 + row, n = nw + ch * 8;
+                        if (m < p.M && n < p.N)
+                            *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(p.C) + p.c.off(m) + n) = o;
+                    }
+                }
+        } else {
+            // fp32 staging, 16 rows x 256 B per round; 16-B chunk c of row r lives at chunk c ^ r.  After
+            // the transpose a lane owns 4 consecutive columns of rows 4 it + g4: the residual (fp32 or bf16,
+            // possibly the output buffer itself) is read and the result stored as whole row segments, rounded
+            // once.  The residual of round k+1 is requested before the stores of round k are issued, so no
+            // round waits for a full memory round trip behind its predecessor's stores.
+            if (EPI == 2) {
+                // bf16 residual stream updated in place: a lane owns 8 consecutive columns (16 B of bf16)
+                // of rows 8 it + (lane >> 3); two staged fp32 chunks + one 16-B residual load per store.
+                u32x4 rcur[2], rnxt[2];
+                auto res_load8 = [&](int rnd, u32x4(&rr)[2]) {
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        const int m = mw + rnd * 16 + it * 8 + (lane >> 3), n = nw + (lane & 7) * 8;
+                        rr[it] = (m < p.M && n < p.N)
+                                     ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const __bf16*>(p.res) + p.r.off(m) + n)
+                                     : u32x4{0u, 0u, 0u, 0u};
+                    }
+                };
+                res_load8(0, rcur);
+#pragma unroll
+                for (int rnd = 0; rnd < 8; ++rnd) {
+                    const int mh = rnd >> 2, i = rnd & 3;
+#pragma unroll
+                    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int ch = nh * 8 + j * 4 + g4;
+                            *reinterpret_cast<f32x4*>(stg + r16 * 256 + ((ch ^ r16) << 4)) = pre(acc[mh][nh][i][j], nh, j);
+                        }
+                    if (rnd < 7) res_load8(rnd + 1, rnxt);
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        const int row = it * 8 + (lane >> 3), c8 = lane & 7;
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(stg + row * 256 + (((2 * c8) ^ row) << 4));
+                        const f32x4 b = *reinterpret_cast<const f32x4*>(stg + row * 256 + (((2 * c8 + 1) ^ row) << 4));
+                        const int m = mw + rnd * 16 + row, n = nw + c8 * 8;
+                        if (m < p.M && n < p.N) {
+                            const u32x4 r = rcur[it];
+                            u32x4 o;
+                            o[0] = pack_bf16x2(a[0] + bf16_lo(r[0]), a[1] + bf16_hi(r[0]));
+                            o[1] = pack_bf16x2(a[2] + bf16_lo(r[1]), a[3] + bf16_hi(r[1]));
+                            o[2] = pack_bf16x2(b[0] + bf16_lo(r[2]), b[1] + bf16_hi(r[2]));
+                            o[3] = pack_bf16x2(b[2] + bf16_lo(r[3]), b[3] + bf16_hi(r[3]));
+                            *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(p.C) + p.c.off(m) + n) = o;
+                        }
+                    }
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) rcur[it] = rnxt[it];
+                }
+                return;
+            }
+            f32x4 rcur[4], rnxt[4];
+            auto res_load = [&](int rnd, f32x4(&rr)[4]) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int m = mw + rnd * 16 + it * 4 + g4, n = nw + r16 * 4;
+                    rr[it] = (m < p.M && n < p.N) ? load_res4(p, p.r.off(m) + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            };
+            if (p.res) res_load(0, rcur);
+#pragma unroll
+            for (int rnd = 0; rnd < 8; ++rnd) {
+                const int mh = rnd >> 2, i = rnd & 3;
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int ch = nh * 8 + j * 4 + g4;
+                        *reinterpret_cast<f32x4*>(stg + r16 * 256 + ((ch ^ r16) << 4)) = pre(acc[mh][nh][i][j], nh, j);
+                    }
+                if (p.res && rnd < 7) res_load(rnd + 1, rnxt);
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int row = it * 4 + g4, ch = r16;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * 256 + ((ch ^ row) << 4));
+                    const int m = mw + rnd * 16 + row, n = nw + ch * 4;
+                    if (m < p.M && n < p.N) {
+                        if (p.res) v += rcur[it];
+                        if (p.out_f32) {
+                            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + p.c.off(m) + n) = v;
+                        } else {
+                            u32x2 o;
+                            o[0] = pack_bf16x2(v[0], v[1]);
+                            o[1] = pack_bf16x2(v[2], v[3]);
+                            *reinterpret_cast<u32x2*>(reinterpret_cast<__bf16*>(p.C) + p.c.off(m) + n) = o;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) rcur[it] = rnxt[it];
+            }
+        }
+    };
+
+    // ---- prologue: K-tile 0 of the stream complete, A-half0 of K-tile 1 in flight ----
+    stage(0);
+    stage(1);
+    stage(2);
+    stage(3);
+    if (stage(0)) {
         asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -213,61 +440,47 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
     HK_BAR();
     if (wm == 1) HK_BAR();  // stagger group 1 by one barrier
 
-    for (int t = 0; t < KT; ++t) {
-        const int buf = t & 1;
-        const bool n1 = t + 1 < KT;
-        // phase 1
-        load_a(buf, 0);
-        load_w(buf, 0);
-        if (n1) stage(1, t + 1);
-        HK_MMA(0, 0);
-        // phase 2
-        load_w(buf, 1);
-        if (n1) stage(2, t + 1);
-        HK_MMA(0, 1);
-        // phase 3
-        load_a(buf, 1);
-        if (n1) stage(3, t + 1);
-        HK_MMA(1, 1);
-        // phase 4
-        load_w(buf, 0);
-        if (t + 2 < KT) {
-            stage(0, t + 2);
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long* trc = p.trace ? p.trace + (size_t)blockIdx.x * 64 : nullptr;
+    if (trc && tid == 0) {
+        trc[0] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
+        trc[1] = __builtin_amdgcn_s_memrealtime();
+    }
+    int buf = 0;
+    for (int ti = 0; ti < ntile; ++ti) {
+        for (int t = 0; t < KT; ++t) {
+            // phase 1
+            load_a(buf, 0);
+            load_w(buf, 0);
+            stage(1);
+            HK_MMA(0, 0);
+            // phase 2
+            load_w(buf, 1);
+            stage(2);
+            HK_MMA(0, 1);
+            // phase 3
+            load_a(buf, 1);
+            stage(3);
+            HK_MMA(1, 1);
+            // phase 4
+            load_w(buf, 0);
+            if (stage(0)) {
+                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            HK_MMA(1, 0);
+            buf ^= 1;
         }
-        HK_MMA(1, 0);
+        const int lid = c0 + jb + ti * nbx;
+        if (trc && tid == 0 && ti < 31) trc[2 + 2 * ti] = __builtin_amdgcn_s_memrealtime();
+        int tm, tn;
+        tile_coords(lid, p.nbm, p.nbn, p.gm, tm, tn);
+        epilogue(tm * 256, tn * 256);
+        if (trc && tid == 0 && ti < 31) trc[3 + 2 * ti] = __builtin_amdgcn_s_memrealtime();
+        zero_acc();
     }
     if (wm == 0) HK_BAR();  // equalise the barrier count of the two groups
 #undef HK_MMA
-
-    // ---- epilogue ----
-#pragma unroll
-    for (int nh = 0; nh < 2; ++nh) {
-        f32x4 bias[2];
-        const int ncol = n0 + wn * 64 + nh * 32 + (lane >> 4) * 4;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = ncol + j * 16;
-            bias[j] = (p.bias != nullptr && n < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + n)
-                                                     : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = m0 + wm * 128 + mh * 64 + i * 16 + (lane & 15);
-                if (m >= p.M) continue;
-                const int64_t coff = p.c.off(m);
-                const int64_t roff = p.res ? p.r.off(m) : 0;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int n = ncol + j * 16;
-                    if (n < p.N) epi_store(p, acc[mh][nh][i][j], bias[j], n, coff, roff);
-                }
-            }
-    }
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -390,7 +603,7 @@ __global__ __launch_bounds__(WM* WN * 64) void hk_gemm_kernel(const GemmParams p
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
             }
-            if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + roff + n);
+            if (p.res) v += load_res4(p, roff + n);
             if (p.out_f32) {
                 *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + coff + n) = v;
             } else {
@@ -424,23 +637,51 @@ int launch(const GemmParams& p, hipStream_t stream) {
     return HK_OK;
 }
 
+template <int EPI>
 int launch_pp(const GemmParams& p, hipStream_t stream) {
-    constexpr int LDS = 2 * 4 * 128 * 64 * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hk_gemm_pp_kernel),
+    constexpr int LDS = 2 * 4 * 128 * 64 * 2 + 8 * 4096;  // operand buffers + epilogue staging = 160 KB
+    static int ncu = 0;  // idempotent; racing first calls compute the same values
+    if (ncu == 0) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hk_gemm_pp_kernel<EPI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) {
-            hk_set_error("hk_gemm_bf16: hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e));
+        int dev = 0, n = 0;
+        if (e == hipSuccess) e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess || n <= 0) {
+            hk_set_error("hk_gemm_bf16: device setup (%d B LDS): %s", LDS, hipGetErrorString(e));
             return HK_ELAUNCH;
         }
-        attr_set = true;
+        ncu = n;
     }
     GemmParams q = p;
     q.nbm = (p.M + 255) / 256;
     q.nbn = (p.N + 255) / 256;
-    hipLaunchKernelGGL(hk_gemm_pp_kernel, dim3(q.nbm * q.nbn), dim3(512), LDS, stream, q);
+    const int ntiles = q.nbm * q.nbn;
+    // HK_GEMM_VARIANT=2: one tile per workgroup (grid = tiles) instead of the persistent walk
+    static const int variant = getenv("HK_GEMM_VARIANT") ? atoi(getenv("HK_GEMM_VARIANT")) : 1;
+    const int grid = (variant == 2 || ntiles < ncu) ? ntiles : ncu;
+    // HK_GEMM_TRACE=<file>: debug only -- per-workgroup timestamps of the LAST launch are dumped (this path
+    // allocates and synchronises; never set it in production)
+    static const char* trace_path = getenv("HK_GEMM_TRACE");
+    static unsigned long long* trace_buf = nullptr;
+    if (trace_path) {
+        if (!trace_buf && hipMalloc(&trace_buf, (size_t)16384 * 64 * 8) != hipSuccess) trace_buf = nullptr;
+        if (trace_buf) hipMemsetAsync(trace_buf, 0, (size_t)16384 * 64 * 8, stream);
+        q.trace = grid <= 16384 ? trace_buf : nullptr;
+    }
+    hipLaunchKernelGGL(hk_gemm_pp_kernel<EPI>, dim3(grid), dim3(512), LDS, stream, q);
     HK_CHECK_LAUNCH("hk_gemm_bf16");
+    if (trace_path && q.trace) {
+        hipStreamSynchronize(stream);
+        unsigned long long* h = (unsigned long long*)malloc((size_t)grid * 64 * 8);
+        hipMemcpy(h, trace_buf, (size_t)grid * 64 * 8, hipMemcpyDeviceToHost);
+        FILE* f = fopen(trace_path, "wb");
+        if (f) {
+            fwrite(h, 8, (size_t)grid * 64, f);
+            fclose(f);
+        }
+        free(h);
+    }
     return HK_OK;
 }
 
@@ -464,6 +705,8 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
     HK_REQUIRE(d->out_dtype == HK_DT_BF16 || d->out_dtype == HK_DT_F32, "hk_gemm_bf16: unknown out_dtype %d",
                d->out_dtype);
     HK_REQUIRE(d->scale_cols % 4 == 0, "hk_gemm_bf16: scale_cols must be a multiple of 4");
+    HK_REQUIRE(d->res_dtype == HK_DT_BF16 || d->res_dtype == HK_DT_F32, "hk_gemm_bf16: unknown res_dtype %d",
+               d->res_dtype);
 
     GemmParams p;
     p.A = reinterpret_cast<const __bf16*>(d->A);
@@ -480,14 +723,25 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
     p.ldw = d->ldw;
     p.act = d->act;
     p.out_f32 = d->out_dtype == HK_DT_F32;
+    p.res_bf16 = d->res_dtype == HK_DT_BF16;
     p.scale_cols = d->scale_cols;
     p.scale = d->scale;
     p.nbm = p.nbn = 0;
+    p.trace = nullptr;
+    static const int dbg = getenv("HK_GEMM_DEBUG") ? atoi(getenv("HK_GEMM_DEBUG")) : 0;
+    p.dbg = dbg;
+    static const int gm = getenv("HK_GEMM_GM") ? atoi(getenv("HK_GEMM_GM")) : 4;
+    p.gm = gm < 1 ? 1 : gm;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 
     // Big tiles once they fill the chip; 128x128 (2 workgroups per CU) for the small Q-Former GEMMs.
     const long tiles256 = (long)((d->M + 255) / 256) * ((d->N + 255) / 256);
     static const int variant = getenv("HK_GEMM_VARIANT") ? atoi(getenv("HK_GEMM_VARIANT")) : 1;
-    if (tiles256 >= 256 && d->N % 256 == 0) return variant == 0 ? launch<256, 256, 2, 4>(p, s) : launch_pp(p, s);
+    if (tiles256 >= 256 && d->N % 256 == 0) {
+        if (variant == 0) return launch<256, 256, 2, 4>(p, s);
+        if (!p.out_f32 && !p.res) return launch_pp<0>(p, s);
+        if (!p.out_f32 && p.res_bf16) return launch_pp<2>(p, s);
+        return launch_pp<1>(p, s);
+    }
     return launch<128, 128, 2, 2>(p, s);
 }

@@ -9,7 +9,7 @@ is a loop of ctypes calls on the current HIP stream: no allocation, no host
 synchronisation, no PyTorch arithmetic.
 
 Data layout in HBM (row-major, M = B*N image tokens, N = T*L):
-    x      fp32 [M, D]      residual stream of the ViT (updated in place by the proj / fc2 epilogues)
+    x      bf16|fp32 [M, D] residual stream of the ViT (updated in place by the proj / fc2 epilogues)
     xn     bf16 [M, D]      LayerNorm output = GEMM operand
     qkv    bf16 [M, 3D]     columns [q | k | v], head h at h*64 inside each third (vit.py:88)
     att    bf16 [M, D]      attention output, already in the [B,N,H*64] layout proj consumes (vit.py:97)
@@ -44,7 +44,13 @@ class _Plan:
 
 
 class HipEncoderEngine:
-    def __init__(self, cfg: EncoderConfig, device="cuda"):
+    def __init__(self, cfg: EncoderConfig, device="cuda", residual_dtype=torch.bfloat16):
+        """residual_dtype: storage type of the ViT residual stream `x` (bf16 halves the proj / fc2
+        epilogue and LayerNorm traffic; the reference's CUDA autocast path keeps it in fp16).
+        Arithmetic is fp32 either way: each update is acc + bias + float(x), rounded once."""
+        if residual_dtype not in (torch.bfloat16, torch.float32):
+            raise RuntimeError("residual_dtype must be torch.bfloat16 or torch.float32")
+        self.residual_dtype = residual_dtype
         self.cfg = cfg
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -159,7 +165,7 @@ class HipEncoderEngine:
         bf16, f32 = torch.bfloat16, torch.float32
         with torch.cuda.device(dev):
             pa = plan.buf("patches", (M, Kp), bf16, dev)
-            x = plan.buf("x", (M, D), f32, dev)
+            x = plan.buf("x", (M, D), self.residual_dtype, dev)
             xn = plan.buf("xn", (M, D), bf16, dev)
             qkv = plan.buf("qkv", (M, 3 * D), bf16, dev)
             att = plan.buf("att", (M, D), bf16, dev)
@@ -186,25 +192,27 @@ class HipEncoderEngine:
 
         # ---- ViT: patch-embed GEMM (+bias, + position table broadcast over the batch) ----
         # step 0 (patchify) and the table pointer are bound at run time
+        xf32 = self.residual_dtype == torch.float32
+        rkw = dict(out_f32=xf32, res_bf16=not xf32)   # in-place residual-stream update
         plan.patch_desc = self._gemm(plan, P(pa), w["patch.w"], P(x), M, D, Kp, bias=P(w["patch.b"]), residual=0,
-                                     a_rows=plain(Kp), c_rows=plain(D), r_rows=(D, N, 0), out_f32=True)
+                                     a_rows=plain(Kp), c_rows=plain(D), r_rows=(D, N, 0), out_f32=xf32)
         qscale = (64 ** -0.5) * LOG2E
         for i in range(cfg.run_depth):
             o = f"vit.{i}."
-            self._ln(plan, P(x), True, w[o + "ln1.g"], w[o + "ln1.b"], P(xn), None, M, D, cfg.vit_ln_eps)
+            self._ln(plan, P(x), xf32, w[o + "ln1.g"], w[o + "ln1.b"], P(xn), None, M, D, cfg.vit_ln_eps)
             self._gemm(plan, P(xn), w[o + "qkv.w"], P(qkv), M, 3 * D, D, bias=P(w[o + "qkv.b"]),
                        a_rows=plain(D), c_rows=plain(3 * D), scale_cols=D, scale=qscale)
             self._attn(plan, P(qkv), P(qkv) + 2 * D, P(qkv) + 4 * D, P(att), B, Hv, N, N,
                        3 * D, 3 * D, 3 * D, D, N * 3 * D, N * 3 * D, N * 3 * D, N * D)
             self._gemm(plan, P(att), w[o + "proj.w"], P(x), M, D, D, bias=P(w[o + "proj.b"]), residual=P(x),
-                       a_rows=plain(D), c_rows=plain(D), r_rows=plain(D), out_f32=True)
-            self._ln(plan, P(x), True, w[o + "ln2.g"], w[o + "ln2.b"], P(xn), None, M, D, cfg.vit_ln_eps)
+                       a_rows=plain(D), c_rows=plain(D), r_rows=plain(D), **rkw)
+            self._ln(plan, P(x), xf32, w[o + "ln2.g"], w[o + "ln2.b"], P(xn), None, M, D, cfg.vit_ln_eps)
             self._gemm(plan, P(xn), w[o + "fc1.w"], P(hid), M, D * cfg.mlp_ratio, D, bias=P(w[o + "fc1.b"]),
                        a_rows=plain(D), c_rows=plain(D * cfg.mlp_ratio), act=L.HK_ACT_GELU_ERF)
             self._gemm(plan, P(hid), w[o + "fc2.w"], P(x), M, D, D * cfg.mlp_ratio, bias=P(w[o + "fc2.b"]),
-                       residual=P(x), a_rows=plain(D * cfg.mlp_ratio), c_rows=plain(D), r_rows=plain(D), out_f32=True)
+                       residual=P(x), a_rows=plain(D * cfg.mlp_ratio), c_rows=plain(D), r_rows=plain(D), **rkw)
         # vision_layernorm (hawkeye_it.py:234) then the K/V projections of every cross layer at once
-        self._ln(plan, P(x), True, w["vln.g"], w["vln.b"], P(xn), None, M, D, cfg.vision_ln_eps)
+        self._ln(plan, P(x), xf32, w["vln.g"], w["vln.b"], P(xn), None, M, D, cfg.vision_ln_eps)
         self._gemm(plan, P(xn), w["ckv.w"], P(kvc), M, KVW, D, bias=P(w["ckv.b"]), a_rows=plain(D), c_rows=plain(KVW))
 
         # ---- Q-Former ----

@@ -28,7 +28,8 @@ class HkGemmDesc(C.Structure):
         ("A", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p), ("C", C.c_void_p),
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
         ("a_rows", HkRows), ("ldw", C.c_int64), ("c_rows", HkRows), ("r_rows", HkRows),
-        ("act", C.c_int32), ("out_dtype", C.c_int32), ("scale_cols", C.c_int32), ("scale", C.c_float),
+        ("act", C.c_int32), ("out_dtype", C.c_int32), ("res_dtype", C.c_int32), ("scale_cols", C.c_int32),
+        ("scale", C.c_float),
     ]
 
 

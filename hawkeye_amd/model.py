@@ -182,7 +182,7 @@ class HawkEyeEncoder(nn.Module):
     """The hot-path half of HawkEye_it (models/hawkeye_it.py:15-270) on MI355X."""
 
     def __init__(self, cfg: EncoderConfig = EncoderConfig(), tokenizer=None, max_txt_len: int = 512,
-                 out_dtype: torch.dtype = torch.float16):
+                 out_dtype: torch.dtype = torch.float16, residual_dtype: torch.dtype = torch.bfloat16):
         super().__init__()
         self.cfg = cfg
         # registered first: Blip2Base.device is "device of the first parameter" (blip2.py:32-34)
@@ -199,6 +199,7 @@ class HawkEyeEncoder(nn.Module):
         self.max_txt_len = max_txt_len
         self.qformer_text_input = True
         self.low_resource = False
+        self.residual_dtype = residual_dtype   # ViT residual-stream storage (see HipEncoderEngine)
         self.out_dtype = out_dtype        # the reference returns fp16 under its autocast (blip2.py:42)
         self.devices = [torch.device("cuda", 0), torch.device("cuda", 0)]
         self._engine: Optional[HipEncoderEngine] = None
@@ -243,7 +244,7 @@ class HawkEyeEncoder(nn.Module):
         key = (str(dev), self._weights_key())
         if force or self._engine is None or self._engine_key != key:
             if self._engine is None or self._engine.device != dev:
-                self._engine = HipEncoderEngine(self.cfg, dev)
+                self._engine = HipEncoderEngine(self.cfg, dev, self.residual_dtype)
             self._engine.load_state_dict(self.state_dict())
             self._engine_key = key
         return self._engine

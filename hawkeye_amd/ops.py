@@ -30,8 +30,8 @@ def _need(t: torch.Tensor, dtype, name: str):
 
 
 def gemm_desc(A, W, C_out, M, N, K, *, bias=None, residual=None, a_rows: Rows, c_rows: Rows,
-              r_rows: Rows = (0, 0, 0), ldw=None, act=L.HK_ACT_NONE, out_f32=False, scale_cols=0,
-              scale=1.0) -> L.HkGemmDesc:
+              r_rows: Rows = (0, 0, 0), ldw=None, act=L.HK_ACT_NONE, out_f32=False, res_bf16=False,
+              scale_cols=0, scale=1.0) -> L.HkGemmDesc:
     """Raw-pointer descriptor; A/W/C_out/bias/residual are integer device addresses."""
     d = L.HkGemmDesc()
     d.A, d.W, d.bias, d.residual, d.C = A, W, bias, residual, C_out
@@ -42,6 +42,7 @@ def gemm_desc(A, W, C_out, M, N, K, *, bias=None, residual=None, a_rows: Rows, c
     d.r_rows = L.HkRows(*r_rows)
     d.act = act
     d.out_dtype = L.HK_DT_F32 if out_f32 else L.HK_DT_BF16
+    d.res_dtype = L.HK_DT_BF16 if res_bf16 else L.HK_DT_F32
     d.scale_cols = scale_cols
     d.scale = scale
     return d
@@ -64,9 +65,10 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     if bias is not None:
         _need(bias, torch.float32, "bias")
     if residual is not None:
-        _need(residual, torch.float32, "residual")
+        if residual.dtype not in (torch.float32, torch.bfloat16) or not residual.is_cuda:
+            raise RuntimeError("linear: residual must be an fp32 or bf16 GPU tensor")
         if residual.shape != (M, N) or residual.stride(1) != 1:
-            raise RuntimeError("linear: residual must be [M,N] row-major fp32")
+            raise RuntimeError("linear: residual must be [M,N] row-major")
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=x.device)
     _need(out, out_dtype, "out")
@@ -74,6 +76,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
                   a_rows=(x.stride(0), 0, 0), c_rows=(out.stride(0), 0, 0),
                   r_rows=(residual.stride(0), 0, 0) if residual is not None else (0, 0, 0), ldw=w.stride(0),
                   act=L.HK_ACT_GELU_ERF if act == "gelu" else L.HK_ACT_NONE, out_f32=out_dtype == torch.float32,
+                  res_bf16=residual is not None and residual.dtype == torch.bfloat16,
                   scale_cols=scale_cols, scale=scale)
     run_gemm(d)
     return out

@@ -45,7 +45,8 @@ typedef struct hk_rows {
 
 /* C = act((A . W^T + bias) * colscale) + residual
  *   A [M,K] bf16, W [N,K] bf16 (nn.Linear / flattened Conv3d weight layout), bias [N] fp32 or NULL,
- *   residual fp32 or NULL, C bf16 or fp32 (out_dtype).  fp32 accumulation on MFMA.
+ *   residual fp32 or bf16 (res_dtype) or NULL -- it may be C itself (in-place residual stream), C bf16 or
+ *   fp32 (out_dtype).  fp32 accumulation on MFMA; the output is rounded once, after the residual add.
  *   Columns n < scale_cols are multiplied by `scale` after the bias (used to fold the
  *   attention scale into Q: vit.py:91, Qformer.py:257).
  * Replaces: F.linear qkv vit.py:87; proj vit.py:98 + residual vit.py:126; fc1+GELU vit.py:49-50;
@@ -56,7 +57,7 @@ typedef struct hk_gemm_desc {
     const void* A;
     const void* W;
     const float* bias;
-    const float* residual;
+    const void* residual;
     void* C;
     int32_t M, N, K;
     hk_rows a_rows;
@@ -65,6 +66,7 @@ typedef struct hk_gemm_desc {
     hk_rows r_rows;
     int32_t act;        /* HK_ACT_* */
     int32_t out_dtype;  /* HK_DT_* */
+    int32_t res_dtype;  /* HK_DT_* of `residual` */
     int32_t scale_cols;
     float scale;
 } hk_gemm_desc;

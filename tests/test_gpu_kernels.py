@@ -79,6 +79,25 @@ def test_gemm_epilogues_and_row_maps():
     assert _rel(out2, ref2) < 2e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(66000, 1024, 256), (300, 768, 128)])
+def test_gemm_bf16_residual_in_place(M, N, K):
+    """The bf16 residual stream: C = bf16(x @ w.T + b + float(C)), rounded once, C updated in place."""
+    x = _rand((M, K), 81, dtype=torch.bfloat16)
+    w = _rand((N, K), 82, 0.05, dtype=torch.bfloat16)
+    b = _rand((N,), 83)
+    res = _rand((M, N), 84, 2.0, dtype=torch.bfloat16)
+    ref = (x.float() @ w.float().t() + b + res.float()).to(torch.bfloat16)
+    out = res.clone()
+    ops.linear(x, w, b, residual=out, out=out)
+    # single rounding of an fp32 sum that differs from the reference only by summation order
+    diff = (out.float() - ref.float()).abs()
+    assert (diff <= 2 ** -7 * ref.float().abs() + 1e-6).all()
+    assert (out != ref).float().mean().item() < 0.02
+    # fp32 out with bf16 residual
+    o32 = ops.linear(x, w, b, residual=res, out_dtype=torch.float32)
+    assert _rel(o32, x.float() @ w.float().t() + b + res.float()) < 2e-5
+
+
 def test_gemm_rejects_bad_shapes():
     x = _rand((8, 48), 1, dtype=torch.bfloat16)
     w = _rand((16, 48), 2, dtype=torch.bfloat16)

@@ -26,8 +26,8 @@ def _cos(a, b):
     return (a @ b / (a.norm() * b.norm())).item()
 
 
-def _model(cfg, seed, T):
-    m = HawkEyeEncoder(cfg, out_dtype=torch.float32)
+def _model(cfg, seed, T, residual_dtype=torch.bfloat16):
+    m = HawkEyeEncoder(cfg, out_dtype=torch.float32, residual_dtype=residual_dtype)
     missing, unexpected = m.load_state_dict(W.make_state_dict(cfg, seed, depth_in_ckpt=True), strict=False)
     assert not missing
     # the checkpoint's last ViT block is dropped, exactly like the reference's strict=False load
@@ -81,6 +81,18 @@ def test_full_size_goldens(golden_dir, name):
         _check(f"{name}.{stage}.slice", buf[rows][:, cols], g[f"digest.{stage}.slice"])
         l2 = float(g[f"digest.{stage}.l2"])
         assert abs(buf.double().norm().item() - l2) <= 1e-2 * l2
+
+
+def test_fp32_residual_stream_mode(golden_dir):
+    """residual_dtype=float32 keeps the ViT residual stream in fp32 (default is bf16)."""
+    g = np.load(os.path.join(golden_dir, "full_T8_B1.npz"))
+    B, T, seed = int(g["B"]), int(g["T"]), int(g["seed"])
+    m = _model(FULL, seed, T, residual_dtype=torch.float32)
+    image = W.make_clip(B, T, FULL.img_size, seed).to(DEV)
+    ids, mask = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["text_mask"])
+    out, _ = m.encode_img(image, (ids, mask))
+    _check("full_T8_B1.out[fp32 residual]", out, g["out"])
+    assert m._engine.plans[(B, T, ids.shape[1])].ws["x"].dtype == torch.float32
 
 
 def test_against_oracle_same_seed_ragged_batch():

@@ -47,13 +47,17 @@ def bench_attn(B=32, N=3136, H=16):
 def bench_gemm(M=100352):
     for name, N, K, kw in (("qkv", 3072, 1024, {}), ("proj+res", 1024, 1024, {"res": True}),
                            ("fc1+gelu", 4096, 1024, {"act": "gelu"}), ("fc2+res", 1024, 4096, {"res": True}),
-                           ("fc1 noact", 4096, 1024, {}), ("ckv", 9216, 1024, {}), ("patch", 1024, 768, {"res": True})):
+                           ("fc1 noact", 4096, 1024, {}), ("ckv", 9216, 1024, {}), ("patch", 1024, 768, {"res": True}),
+                           ("proj+res16", 1024, 1024, {"res": True, "bf16res": True}),
+                           ("fc2+res16", 1024, 4096, {"res": True, "bf16res": True})):
         x = torch.randn(M, K, device=DEV).to(torch.bfloat16)
         w = (torch.randn(N, K, device=DEV) * 0.03).to(torch.bfloat16)
         b = torch.randn(N, device=DEV)
         res = torch.randn(M, N, device=DEV) if kw.get("res") else None
-        odt = torch.float32 if res is not None else torch.bfloat16
-        out = torch.empty(M, N, device=DEV, dtype=odt)
+        if kw.get("bf16res"):
+            res = res.to(torch.bfloat16)
+        odt = torch.float32 if (res is not None and not kw.get("bf16res")) else torch.bfloat16
+        out = res if kw.get("bf16res") else torch.empty(M, N, device=DEV, dtype=odt)
         us = timeit(lambda: ops.linear(x, w, b, residual=res, act=kw.get("act", "none"), out_dtype=odt, out=out))
         print(f"gemm {name:10s} M={M} N={N} K={K}: {us:9.1f} us  {2.0*M*N*K/us/1e6:8.1f} TFLOP/s", flush=True)
         del x, w, res, out
