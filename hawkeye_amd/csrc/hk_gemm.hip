@@ -46,20 +46,33 @@ struct GemmParams {
     int nbm, nbn;
 };
 
-// erfc(t) = exp2(t * p(t)) on t in [0, 6], |err| <= 3.2e-7 (degree-5 minimax-style fit); exact-erf GELU
-// (nn.GELU default, vit.py:44; ACT2FN["gelu"], Qformer.py:383) to fp32 rounding noise.
-__device__ __forceinline__ float gelu_erf(float x) {
-    const float t = fminf(fabsf(x) * 0.70710678118654752f, 6.0f);
-    float p = 0.00014203831960912794f;
-    p = fmaf(p, t, -0.0036642642226070166f);
-    p = fmaf(p, t, 0.030896173790097237f);
-    p = fmaf(p, t, -0.14969943463802338f);
-    p = fmaf(p, t, -0.9181654453277588f);
-    p = fmaf(p, t, -1.6279250383377075f);
-    const float h = 0.5f * __builtin_amdgcn_exp2f(p * t);  // 0.5 * erfc(|x|/sqrt2)
-    return x * (x > 0.0f ? 1.0f - h : h);
+// Exact-erf GELU (nn.GELU default, vit.py:44; ACT2FN["gelu"], Qformer.py:383) to fp32 rounding noise:
+// erfc(t) = exp2(t * p(t)) on t in [0, 6], |err| <= 3.2e-7 (degree-5 fit), and
+//     gelu(x) = 0.5 x + 0.5 |x| (1 - erfc(|x| / sqrt 2))
+// which needs no sign select.  Written on float2 so hipcc emits v_pk_fma_f32 / v_pk_mul_f32: 8 VALU
+// instructions per element instead of 14.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 gelu_erf2(const f32x2 x) {
+    const f32x2 a = __builtin_elementwise_max(x, -x);
+    f32x2 t = a * 0.70710678118654752f;
+    t = __builtin_elementwise_min(t, f32x2{6.0f, 6.0f});
+    f32x2 p = f32x2{0.00014203831960912794f, 0.00014203831960912794f};
+    p = __builtin_elementwise_fma(p, t, f32x2{-0.0036642642226070166f, -0.0036642642226070166f});
+    p = __builtin_elementwise_fma(p, t, f32x2{0.030896173790097237f, 0.030896173790097237f});
+    p = __builtin_elementwise_fma(p, t, f32x2{-0.14969943463802338f, -0.14969943463802338f});
+    p = __builtin_elementwise_fma(p, t, f32x2{-0.9181654453277588f, -0.9181654453277588f});
+    p = __builtin_elementwise_fma(p, t, f32x2{-1.6279250383377075f, -1.6279250383377075f});
+    const f32x2 q = p * t;
+    f32x2 e;
+    e[0] = __builtin_amdgcn_exp2f(q[0]);
+    e[1] = __builtin_amdgcn_exp2f(q[1]);
+    const f32x2 h = a * 0.5f;
+    return __builtin_elementwise_fma(x, f32x2{0.5f, 0.5f}, __builtin_elementwise_fma(-h, e, h));
 }
-
+__device__ __forceinline__ f32x4 gelu_erf4(const f32x4 v) {
+    const f32x2 lo = gelu_erf2(f32x2{v[0], v[1]}), hi = gelu_erf2(f32x2{v[2], v[3]});
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
 
 // 4 consecutive residual elements (fp32 or bf16) at element offset `off`
 __device__ __forceinline__ f32x4 load_res4(const GemmParams& p, int64_t off) {
@@ -75,10 +88,7 @@ __device__ __forceinline__ void epi_store(const GemmParams& p, f32x4 v, const f3
                                           int64_t roff) {
     v += bias;
     if (n < p.scale_cols) v *= p.scale;
-    if (p.act == HK_ACT_GELU_ERF) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-    }
+    if (p.act == HK_ACT_GELU_ERF) v = gelu_erf4(v);
     if (p.res) v += load_res4(p, roff + n);
     if (p.out_f32) {
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + coff + n) = v;
@@ -294,10 +304,7 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
             const int n = n0 + wn * 64 + nh * 32 + j * 16 + (lane >> 4) * 4;
             v += bias[nh][j];
             if (n < p.scale_cols) v *= p.scale;
-            if (p.act == HK_ACT_GELU_ERF) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-            }
+            if (p.act == HK_ACT_GELU_ERF) v = gelu_erf4(v);
             return v;
         };
         const int mw = m0 + wm * 128;  // first row / column of this wave's sub-tile
@@ -599,10 +606,7 @@ __global__ __launch_bounds__(WM* WN * 64) void hk_gemm_kernel(const GemmParams p
             if (n >= p.N) continue;
             f32x4 v = acc[i][j] + bias[j];
             if (n < p.scale_cols) v *= p.scale;
-            if (p.act == HK_ACT_GELU_ERF) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-            }
+            if (p.act == HK_ACT_GELU_ERF) v = gelu_erf4(v);
             if (p.res) v += load_res4(p, roff + n);
             if (p.out_f32) {
                 *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + coff + n) = v;
