@@ -55,9 +55,25 @@ def main():
     ap.add_argument("--lt", type=int, default=32, help="instruction tokens")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--force-gather", action="store_true", help="run the output all_gather even with one rank (plumbing test)")
     args = ap.parse_args()
 
-    rank, local_rank, world = hdist.init("nccl")
+    # RCCL prints a version banner on stdout when its first communicator comes up; the contract is ONE
+    # JSON line on stdout, so stdout points at stderr until the process group has done a collective.
+    sys.stdout.flush()
+    saved_fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        rank, local_rank, world = hdist.init("nccl")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank)
+            hdist.max_over_ranks(0.0, torch.device("cuda", local_rank))
+            hdist.barrier()
+            torch.cuda.synchronize()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
@@ -77,7 +93,7 @@ def main():
     image = W.make_clip(B, T, cfg.img_size, seed + 100 * rank).to(dev)
     ids, mask = W.make_instruction_ids(B, Lt, cfg.qf_vocab, seed)
     ids, mask = ids.to(dev), mask.to(dev)
-    gather = world > 1 and not args.no_gather
+    gather = (world > 1 and not args.no_gather) or args.force_gather
 
     def step():
         out, _ = model.encode_img(image, (ids, mask))

@@ -20,7 +20,7 @@ def env_world() -> Tuple[int, int, int]:
 
 def init(backend: str = "nccl") -> Tuple[int, int, int]:
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or "RANK" in os.environ) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         kw = {}
         if backend == "nccl":
@@ -39,7 +39,7 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
 
 def gather_outputs(local: torch.Tensor, counts: List[int] = None) -> torch.Tensor:
     """all_gather of per-rank [b_r, nq, C] outputs along the clip dim (equal b_r unless counts given)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return local
     world = dist.get_world_size()
     local = local.contiguous()
@@ -56,7 +56,7 @@ def gather_outputs(local: torch.Tensor, counts: List[int] = None) -> torch.Tenso
 
 
 def max_over_ranks(seconds: float, device) -> float:
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return seconds
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -64,5 +64,5 @@ def max_over_ranks(seconds: float, device) -> float:
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         dist.barrier()
