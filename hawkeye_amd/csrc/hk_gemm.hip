@@ -490,32 +490,32 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
 #undef HK_MMA
 }
 
-template <int BM, int BN, int WM, int WN>
+// Multi-stage kernel for the problems too small for the persistent 256x256 kernel (Q-Former GEMMs, small
+// batches): one BM x BN x 64 tile per workgroup, STAGES LDS buffers, LDS-DMA issued STAGES-1 K-tiles ahead
+// and retired by a counted vmcnt (loads in flight across the one barrier per K-tile).  These shapes are
+// latency-bound -- a K-tile's MFMAs take less time than a load round trip -- so prefetch depth, not tile
+// size, is what matters.
+template <int BM, int BN, int WM, int WN, int STAGES>
 __global__ __launch_bounds__(WM* WN * 64) void hk_gemm_kernel(const GemmParams p) {
     constexpr int NW = WM * WN;
     constexpr int BK = 64;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MI = TM / 16, NJ = TN / 16;
     constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW;
+    constexpr int LPT = A_IT + B_IT;       // LDS-DMA instructions per thread per K-tile
     constexpr int STAGE = (BM + BN) * BK;  // elements per stage
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "loader split");
+    static_assert(STAGES >= 2 && STAGES <= 4 && (STAGES - 2) * LPT < 64, "vmcnt range");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __bf16* lds = reinterpret_cast<__bf16*>(smem);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
 
-    // XCD-aware, bijective block remap: the blocks that share an XCD (blockIdx % 8) get a
-    // contiguous run of tiles, n fastest, so concurrently running tiles share A panels in that L2.
-    const int nwg = p.nbm * p.nbn;
-    int lid;
-    {
-        const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    }
+    const int lid = xcd_remap(blockIdx.x, p.nbm * p.nbn);
     const int m0 = (lid / p.nbn) * BM;
     const int n0 = (lid % p.nbn) * BN;
 
@@ -535,7 +535,6 @@ __global__ __launch_bounds__(WM* WN * 64) void hk_gemm_kernel(const GemmParams p
         const int n = min(n0 + row, p.N - 1);
         bptr[i] = p.W + (int64_t)n * p.ldw + ((lpc ^ ((row >> 1) & 7)) << 3);
     }
-
     auto stage_load = [&](int stage, int kt) {
         __bf16* As = lds + stage * STAGE;
         __bf16* Bs = As + BM * BK;
@@ -558,15 +557,21 @@ __global__ __launch_bounds__(WM* WN * 64) void hk_gemm_kernel(const GemmParams p
         for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int KT = p.K / BK;
-    stage_load(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < KT) stage_load(s, s);
 
+    int slot = 0;
     for (int kt = 0; kt < KT; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < KT) stage_load(cur ^ 1, kt + 1);
-        const __bf16* As = lds + cur * STAGE + (wm * TM) * BK;
-        const __bf16* Bs = lds + cur * STAGE + BM * BK + (wn * TN) * BK;
+        // K-tile kt has landed once at most min(STAGES-2, KT-1-kt) younger tiles are still in flight
+        const int younger = min(STAGES - 2, KT - 1 - kt);
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // everyone's part of tile kt landed; everyone is done reading tile kt-1
+        if (kt + STAGES - 1 < KT) stage_load(slot == 0 ? STAGES - 1 : slot - 1, kt + STAGES - 1);
+        const __bf16* As = lds + slot * STAGE + (wm * TM) * BK;
+        const __bf16* Bs = lds + slot * STAGE + BM * BK + (wn * TN) * BK;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int fo = kk ? foff1 : foff0;
@@ -581,8 +586,7 @@ __global__ __launch_bounds__(WM* WN * 64) void hk_gemm_kernel(const GemmParams p
                 for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        slot = slot + 1 == STAGES ? 0 : slot + 1;
     }
 
     // ---- epilogue: lane owns row (lane & 15) of each 16-row tile and 4 consecutive columns ----
@@ -603,29 +607,17 @@ __global__ __launch_bounds__(WM* WN * 64) void hk_gemm_kernel(const GemmParams p
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int n = ncol + j * 16;
-            if (n >= p.N) continue;
-            f32x4 v = acc[i][j] + bias[j];
-            if (n < p.scale_cols) v *= p.scale;
-            if (p.act == HK_ACT_GELU_ERF) v = gelu_erf4(v);
-            if (p.res) v += load_res4(p, roff + n);
-            if (p.out_f32) {
-                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + coff + n) = v;
-            } else {
-                u32x2 o;
-                o[0] = pack_bf16x2(v[0], v[1]);
-                o[1] = pack_bf16x2(v[2], v[3]);
-                *reinterpret_cast<u32x2*>(reinterpret_cast<__bf16*>(p.C) + coff + n) = o;
-            }
+            if (n < p.N) epi_store(p, acc[i][j], bias[j], n, coff, roff);
         }
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int STAGES>
 int launch(const GemmParams& p, hipStream_t stream) {
-    constexpr int LDS = 2 * (BM + BN) * 64 * 2;
+    constexpr int LDS = STAGES * (BM + BN) * 64 * 2;
     static bool attr_set = false;  // idempotent; racing first calls set the same value
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hk_gemm_kernel<BM, BN, WM, WN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hk_gemm_kernel<BM, BN, WM, WN, STAGES>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) {
             hk_set_error("hk_gemm_bf16: hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e));
@@ -636,7 +628,7 @@ int launch(const GemmParams& p, hipStream_t stream) {
     GemmParams q = p;
     q.nbm = (p.M + BM - 1) / BM;
     q.nbn = (p.N + BN - 1) / BN;
-    hipLaunchKernelGGL((hk_gemm_kernel<BM, BN, WM, WN>), dim3(q.nbm * q.nbn), dim3(WM * WN * 64), LDS, stream, q);
+    hipLaunchKernelGGL((hk_gemm_kernel<BM, BN, WM, WN, STAGES>), dim3(q.nbm * q.nbn), dim3(WM * WN * 64), LDS, stream, q);
     HK_CHECK_LAUNCH("hk_gemm_bf16");
     return HK_OK;
 }
@@ -738,14 +730,17 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
     p.gm = gm < 1 ? 1 : gm;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 
-    // Big tiles once they fill the chip; 128x128 (2 workgroups per CU) for the small Q-Former GEMMs.
+    // The persistent 256x256 kernel once its tiles fill the chip; otherwise the multi-stage kernel, with the
+    // narrower 128x64 tile when 128x128 tiles would leave most CUs idle.  HK_GEMM_VARIANT=0 forces the
+    // multi-stage kernel everywhere (A/B aid).
     const long tiles256 = (long)((d->M + 255) / 256) * ((d->N + 255) / 256);
+    const long tiles128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
     static const int variant = getenv("HK_GEMM_VARIANT") ? atoi(getenv("HK_GEMM_VARIANT")) : 1;
-    if (tiles256 >= 256 && d->N % 256 == 0) {
-        if (variant == 0) return launch<256, 256, 2, 4>(p, s);
+    if (variant != 0 && tiles256 >= 256 && d->N % 256 == 0) {
         if (!p.out_f32 && !p.res) return launch_pp<0>(p, s);
         if (!p.out_f32 && p.res_bf16) return launch_pp<2>(p, s);
         return launch_pp<1>(p, s);
     }
-    return launch<128, 128, 2, 2>(p, s);
+    if (tiles128 >= 128) return launch<128, 128, 2, 2, 4>(p, s);
+    return launch<128, 64, 2, 2, 4>(p, s);
 }

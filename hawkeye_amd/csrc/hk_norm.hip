@@ -87,6 +87,60 @@ __global__ __launch_bounds__(256) void hk_layernorm_kernel(const void* xin, cons
     ln_finish<NCH>(x, D, lane, gamma, beta, eps, out_b ? out_b + oo : nullptr, out_f ? out_f + oo : nullptr);
 }
 
+// bf16 -> bf16 fast path (the ViT's residual stream): 16 bytes per lane per access, 8 elements per chunk.
+template <int NCH8>
+__global__ __launch_bounds__(256) void hk_ln_bf16_kernel(const __bf16* xin, const float* gamma, const float* beta,
+                                                         __bf16* out, int64_t rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[NCH8][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH8; ++c) {
+        const int i = (c * 64 + lane) * 8;
+        if (i < D) {
+            const u32x4 w = *reinterpret_cast<const u32x4*>(xin + row * D + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[c][2 * e] = bf16_lo(w[e]);
+                v[c][2 * e + 1] = bf16_hi(w[e]);
+                s += v[c][2 * e] + v[c][2 * e + 1];
+            }
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH8; ++c)
+        if ((c * 64 + lane) * 8 < D) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = v[c][e] - mean;
+                q += d * d;
+            }
+        }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int c = 0; c < NCH8; ++c) {
+        const int i = (c * 64 + lane) * 8;
+        if (i < D) {
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + i), g1 = *reinterpret_cast<const f32x4*>(gamma + i + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + i), b1 = *reinterpret_cast<const f32x4*>(beta + i + 4);
+            float y[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[e] = (v[c][e] - mean) * rstd * g0[e] + b0[e];
+                y[4 + e] = (v[c][4 + e] - mean) * rstd * g1[e] + b1[e];
+            }
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(y[2 * e], y[2 * e + 1]);
+            *reinterpret_cast<u32x4*>(out + row * D + i) = o;
+        }
+    }
+}
+
 template <int NCH>
 __global__ __launch_bounds__(256) void hk_qf_embed_kernel(const float* query, const float* wemb, const float* pemb,
                                                           const int64_t* ids, const float* gamma, const float* beta,
@@ -187,6 +241,16 @@ extern "C" int hk_layernorm(const void* x, int32_t in_dtype, const float* add, c
     const int64_t o_rpb = out_rows ? out_rows->rows_per_batch : 0;
     const int64_t o_bs = out_rows ? out_rows->batch_stride : 0;
     HK_REQUIRE(o_ld >= D && o_ld % 4 == 0 && o_bs % 4 == 0 && o_rpb >= 0, "hk_layernorm: bad out_rows mapping");
+    if (ib && !add && out_bf16 && !out_f32 && !out_rows && D % 8 == 0 && D <= 2048) {
+        const dim3 grid((unsigned)((rows + 3) / 4));
+        const __bf16* xb = reinterpret_cast<const __bf16*>(x);
+        const int n8 = (D + 511) / 512;
+        if (n8 <= 1) hipLaunchKernelGGL((hk_ln_bf16_kernel<1>), grid, dim3(256), 0, s, xb, gamma, beta, ob, rows, D, eps);
+        else if (n8 <= 2) hipLaunchKernelGGL((hk_ln_bf16_kernel<2>), grid, dim3(256), 0, s, xb, gamma, beta, ob, rows, D, eps);
+        else hipLaunchKernelGGL((hk_ln_bf16_kernel<4>), grid, dim3(256), 0, s, xb, gamma, beta, ob, rows, D, eps);
+        HK_CHECK_LAUNCH("hk_layernorm");
+        return HK_OK;
+    }
     const int nch = (D + 255) / 256;
     if (nch <= 1) launch_ln<1>(ib, x, add, gamma, beta, ob, out_f32, rows, D, eps, s, o_ld, o_rpb, o_bs);
     else if (nch <= 2) launch_ln<2>(ib, x, add, gamma, beta, ob, out_f32, rows, D, eps, s, o_ld, o_rpb, o_bs);

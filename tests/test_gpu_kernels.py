@@ -174,6 +174,17 @@ def test_layernorm(D, eps, in_bf16):
     assert _rel(ob2.float(), ref2) < 5e-3
 
 
+@pytest.mark.parametrize("D", [1024, 256, 768])
+def test_layernorm_bf16_fast_path(D):
+    rows = 4099
+    x = (_rand((rows, D), 46, 3.0) + 0.5).to(torch.bfloat16)
+    g, b = _rand((D,), 47) * 0.1 + 1.0, _rand((D,), 48) * 0.1
+    ob, _ = ops.layernorm(x, g, b, 1e-6)
+    ref = torch.nn.functional.layer_norm(x.float(), (D,), g, b, 1e-6)
+    assert _rel(ob.float(), ref) < 5e-3
+    assert (ob.float() - ref).abs().max().item() < 0.05
+
+
 def test_layernorm_out_row_map():
     B, S, nq, D = 3, 20, 8, 128
     x = _rand((B * nq, D), 45)

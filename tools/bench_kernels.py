@@ -67,7 +67,10 @@ def bench_ln(M=100352, D=1024):
     x = torch.randn(M, D, device=DEV)
     g, b = torch.ones(D, device=DEV), torch.zeros(D, device=DEV)
     us = timeit(lambda: ops.layernorm(x, g, b, 1e-6))
-    print(f"ln M={M} D={D}: {us:8.1f} us  {M*D*6/us/1e6:6.2f} TB/s", flush=True)
+    print(f"ln f32->bf16 M={M} D={D}: {us:8.1f} us  {M*D*6/us/1e6:6.2f} TB/s", flush=True)
+    xb = x.to(torch.bfloat16)
+    us = timeit(lambda: ops.layernorm(xb, g, b, 1e-6))
+    print(f"ln bf16->bf16 M={M} D={D}: {us:8.1f} us  {M*D*4/us/1e6:6.2f} TB/s", flush=True)
 
 
 if __name__ == "__main__":
