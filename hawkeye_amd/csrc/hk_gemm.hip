@@ -741,6 +741,7 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
         if (!p.out_f32 && p.res_bf16) return launch_pp<2>(p, s);
         return launch_pp<1>(p, s);
     }
+    if (tiles128 >= 384) return launch<128, 128, 2, 2, 2>(p, s);  // >= 1.5 workgroups per CU: 2 stages, 2 workgroups per CU
     if (tiles128 >= 128) return launch<128, 128, 2, 2, 4>(p, s);
     return launch<128, 64, 2, 2, 4>(p, s);
 }
