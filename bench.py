@@ -20,7 +20,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 from hawkeye_amd import dist as hdist  # noqa: E402
-from hawkeye_amd import posembed, weights as W  # noqa: E402
+from hawkeye_amd import ops, posembed, weights as W  # noqa: E402
 from hawkeye_amd.config import FULL  # noqa: E402
 from hawkeye_amd.engine import flops_per_clip  # noqa: E402
 from hawkeye_amd.model import HawkEyeEncoder  # noqa: E402
@@ -148,6 +148,35 @@ def main():
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "gflop_per_clip": round(fl / 1e9, 1), "device_ms_per_step": round(step_s * 1e3, 3)},
         }
+        # per-kernel roofline, in situ: one HIP event pair around every launch of 3 more calls (same stream and
+        # order as the timed steps); algorithmic flops per launch from SURVEY.md §8d's formula terms
+        N_, D_, R_ = T * cfg.patches_per_frame, cfg.encoder_embed_dim, B * T * cfg.patches_per_frame
+        kflops = {"vit.qkv": 2.0 * R_ * D_ * 3 * D_, "vit.attn": 4.0 * B * N_ * N_ * D_, "vit.proj": 2.0 * R_ * D_ * D_,
+                  "vit.fc1_gelu": 2.0 * R_ * D_ * 4 * D_, "vit.fc2": 2.0 * R_ * D_ * 4 * D_,
+                  "vit.patch_embed": 2.0 * R_ * cfg.patch_k * D_,
+                  "qformer.cross_kv": 2.0 * R_ * D_ * 2 * cfg.qf_hidden * 6}
+        eng = model.sync_engine()
+        table = model._table(T == 1, N_, dev)
+        prof = eng.profile(image, ids, mask, table, reps=3)
+        kern, tot_us = {}, sum(n * us for n, us in prof.values())
+        for tag, (n, us) in sorted(prof.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+            e = {"launches": n, "us": round(us, 1), "share": round(n * us / tot_us, 4)}
+            if tag in kflops:
+                e["tflops"] = round(kflops[tag] / us / 1e6, 1)
+                e["frac"] = round(kflops[tag] / us / 1e6 / PEAK_BF16_TFLOPS, 4)
+            elif tag in ("vit.ln", "vision_layernorm"):
+                nbytes = R_ * D_ * (2 + (2 if eng.residual_dtype == torch.bfloat16 else 4))
+                e["tb_s"] = round(nbytes / us / 1e6, 2)
+                e["frac_hbm"] = round(nbytes / us / 1e6 / 8.0, 4)
+            kern[tag] = e
+        dom = next(iter(kern))
+        res["roofline"]["dominant_kernel"] = dict(kern[dom], tag=dom)
+        res["roofline"]["kernels"] = kern
+        # register-resident MFMA probe on this chip: what the silicon sustains with random / zero data
+        mp = {"16x16x32_random": round(ops.mfma_probe_tflops(0), 1), "16x16x32_zeros": round(ops.mfma_probe_tflops(0, zeros=True), 1),
+              "32x32x16_random": round(ops.mfma_probe_tflops(1), 1)}
+        res["roofline"]["measured_mfma_peak"] = mp
+        res["roofline"]["frac_of_measured_peak"] = round(achieved / max(mp["16x16x32_random"], 1e-9), 4)
         if not args.no_cpu_baseline:
             base, ref = cpu_baseline(sd, T, Lt, seed)
             res["cpu_baseline"] = base

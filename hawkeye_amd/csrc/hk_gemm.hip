@@ -44,6 +44,7 @@ struct GemmParams {
     unsigned long long* trace;  // debug: per workgroup [hwid, t_start, then (t_loop_end, t_epi_end) per tile]
     float scale;
     int nbm, nbn;
+    int m_off;  // multi-stage kernel only: logical row of this launch's row 0 (tail launch of a split problem)
 };
 
 // Exact-erf GELU (nn.GELU default, vit.py:44; ACT2FN["gelu"], Qformer.py:383) to fp32 rounding noise:
@@ -527,7 +528,7 @@ __global__ __launch_bounds__(WM* WN * 64) void hk_gemm_kernel(const GemmParams p
     for (int i = 0; i < A_IT; ++i) {
         const int row = (i * NW + wave) * 8 + lrow;
         const int m = min(m0 + row, p.M - 1);
-        aptr[i] = p.A + p.a.off(m) + ((lpc ^ ((row >> 1) & 7)) << 3);
+        aptr[i] = p.A + p.a.off(m + p.m_off) + ((lpc ^ ((row >> 1) & 7)) << 3);
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
@@ -602,8 +603,8 @@ __global__ __launch_bounds__(WM* WN * 64) void hk_gemm_kernel(const GemmParams p
     for (int i = 0; i < MI; ++i) {
         const int m = m0 + wm * TM + i * 16 + (lane & 15);
         if (m >= p.M) continue;
-        const int64_t coff = p.c.off(m);
-        const int64_t roff = p.res ? p.r.off(m) : 0;
+        const int64_t coff = p.c.off(m + p.m_off);
+        const int64_t roff = p.res ? p.r.off(m + p.m_off) : 0;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int n = ncol + j * 16;
@@ -662,15 +663,15 @@ int launch_pp(const GemmParams& p, hipStream_t stream) {
     static unsigned long long* trace_buf = nullptr;
     if (trace_path) {
         if (!trace_buf && hipMalloc(&trace_buf, (size_t)16384 * 64 * 8) != hipSuccess) trace_buf = nullptr;
-        if (trace_buf) hipMemsetAsync(trace_buf, 0, (size_t)16384 * 64 * 8, stream);
+        if (trace_buf) (void)hipMemsetAsync(trace_buf, 0, (size_t)16384 * 64 * 8, stream);
         q.trace = grid <= 16384 ? trace_buf : nullptr;
     }
     hipLaunchKernelGGL(hk_gemm_pp_kernel<EPI>, dim3(grid), dim3(512), LDS, stream, q);
     HK_CHECK_LAUNCH("hk_gemm_bf16");
     if (trace_path && q.trace) {
-        hipStreamSynchronize(stream);
+        (void)hipStreamSynchronize(stream);
         unsigned long long* h = (unsigned long long*)malloc((size_t)grid * 64 * 8);
-        hipMemcpy(h, trace_buf, (size_t)grid * 64 * 8, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(h, trace_buf, (size_t)grid * 64 * 8, hipMemcpyDeviceToHost);
         FILE* f = fopen(trace_path, "wb");
         if (f) {
             fwrite(h, 8, (size_t)grid * 64, f);
@@ -723,6 +724,7 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
     p.scale_cols = d->scale_cols;
     p.scale = d->scale;
     p.nbm = p.nbn = 0;
+    p.m_off = 0;
     p.trace = nullptr;
     static const int dbg = getenv("HK_GEMM_DEBUG") ? atoi(getenv("HK_GEMM_DEBUG")) : 0;
     p.dbg = dbg;
@@ -734,14 +736,45 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
     // narrower 128x64 tile when 128x128 tiles would leave most CUs idle.  HK_GEMM_VARIANT=0 forces the
     // multi-stage kernel everywhere (A/B aid).
     const long tiles256 = (long)((d->M + 255) / 256) * ((d->N + 255) / 256);
-    const long tiles128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
     static const int variant = getenv("HK_GEMM_VARIANT") ? atoi(getenv("HK_GEMM_VARIANT")) : 1;
+    auto small = [&](const GemmParams& q) {
+        const long t128 = (long)((q.M + 127) / 128) * ((q.N + 127) / 128);
+        if (t128 >= 384) return launch<128, 128, 2, 2, 2>(q, s);  // >= 1.5 workgroups per CU: 2 stages, 2 workgroups per CU
+        if (t128 >= 128) return launch<128, 128, 2, 2, 4>(q, s);
+        return launch<128, 64, 2, 2, 4>(q, s);
+    };
     if (variant != 0 && tiles256 >= 256 && d->N % 256 == 0) {
-        if (!p.out_f32 && !p.res) return launch_pp<0>(p, s);
-        if (!p.out_f32 && p.res_bf16) return launch_pp<2>(p, s);
-        return launch_pp<1>(p, s);
+        // Tail balance: the persistent kernel gives each of the 256 CUs floor or ceil(tiles / 256) tiles, so a
+        // last round that is less than half full (e.g. 1568 tiles = 6.125 rounds) idles most of the chip for a
+        // whole tile time.  Then the rows of that partial round go to the multi-stage kernel as a second
+        // launch (its own tile raster spreads them over all CUs) and the persistent kernel runs whole rounds.
+        static const int split = getenv("HK_GEMM_SPLIT") ? atoi(getenv("HK_GEMM_SPLIT")) : 1;
+        static int ncu = 0;  // idempotent
+        if (ncu == 0) {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+                n = 256;
+            ncu = n;
+        }
+        const int nbn = d->N / 256, nbm = (d->M + 255) / 256;
+        const long rem = tiles256 % ncu;
+        GemmParams tail = p;
+        tail.M = 0;
+        if (split && rem != 0 && rem < ncu / 2 && tiles256 >= 2 * ncu) {
+            const int rows_main = (int)((tiles256 - rem) / nbn);   // whole tile rows inside the full rounds
+            if (rows_main > 0 && rows_main < nbm) {
+                tail.m_off = rows_main * 256;
+                tail.M = d->M - tail.m_off;
+                p.M = tail.m_off;
+            }
+        }
+        int rc;
+        if (!p.out_f32 && !p.res) rc = launch_pp<0>(p, s);
+        else if (!p.out_f32 && p.res_bf16) rc = launch_pp<2>(p, s);
+        else rc = launch_pp<1>(p, s);
+        if (rc != HK_OK || tail.M == 0) return rc;
+        return small(tail);
     }
-    if (tiles128 >= 384) return launch<128, 128, 2, 2, 2>(p, s);  // >= 1.5 workgroups per CU: 2 stages, 2 workgroups per CU
-    if (tiles128 >= 128) return launch<128, 128, 2, 2, 4>(p, s);
-    return launch<128, 64, 2, 2, 4>(p, s);
+    return small(p);
 }

@@ -62,6 +62,7 @@ class HipEncoderEngine:
         self.w: Dict[str, torch.Tensor] = {}
         self.plans: Dict[Tuple[int, int, int], _Plan] = {}
         self.n_cross = len([i for i in range(cfg.qf_layers) if i % cfg.cross_attention_freq == 0])
+        self._tag = ""          # label of the plan steps being appended (profile() groups by it)
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):
@@ -132,13 +133,13 @@ class HipEncoderEngine:
     def _gemm(self, plan, A, W, Cout, M, N, K, **kw):
         d = ops.gemm_desc(A, W.data_ptr(), Cout, M, N, K, **kw)
         plan.keep.append(d)
-        plan.steps.append((self.lib.hk_gemm_bf16, (C.byref(d),), "hk_gemm_bf16"))
+        plan.steps.append((self.lib.hk_gemm_bf16, (C.byref(d),), "hk_gemm_bf16", self._tag))
         return d
 
     def _attn(self, plan, *a, **kw):
         d = ops.attn_desc(*a, **kw)
         plan.keep.append(d)
-        plan.steps.append((self.lib.hk_flash_attn_bf16, (C.byref(d),), "hk_flash_attn_bf16"))
+        plan.steps.append((self.lib.hk_flash_attn_bf16, (C.byref(d),), "hk_flash_attn_bf16", self._tag))
 
     def _ln(self, plan, x, in_f32, gamma, beta, ob, of, rows, D, eps, out_rows=None):
         orow = None
@@ -148,7 +149,7 @@ class HipEncoderEngine:
             orow = C.byref(r)
         plan.steps.append((self.lib.hk_layernorm,
                            (x, L.HK_DT_F32 if in_f32 else L.HK_DT_BF16, None, gamma.data_ptr(), beta.data_ptr(),
-                            ob, of, orow, rows, D, eps), "hk_layernorm"))
+                            ob, of, orow, rows, D, eps), "hk_layernorm", self._tag))
 
     def _build_plan(self, B: int, T: int, Lt: int) -> _Plan:
         cfg, dev, w = self.cfg, self.device, self.w
@@ -194,32 +195,43 @@ class HipEncoderEngine:
         # step 0 (patchify) and the table pointer are bound at run time
         xf32 = self.residual_dtype == torch.float32
         rkw = dict(out_f32=xf32, res_bf16=not xf32)   # in-place residual-stream update
+        self._tag = "vit.patch_embed"
         plan.patch_desc = self._gemm(plan, P(pa), w["patch.w"], P(x), M, D, Kp, bias=P(w["patch.b"]), residual=0,
                                      a_rows=plain(Kp), c_rows=plain(D), r_rows=(D, N, 0), out_f32=xf32)
         qscale = (64 ** -0.5) * LOG2E
         for i in range(cfg.run_depth):
             o = f"vit.{i}."
+            self._tag = "vit.ln"
             self._ln(plan, P(x), xf32, w[o + "ln1.g"], w[o + "ln1.b"], P(xn), None, M, D, cfg.vit_ln_eps)
+            self._tag = "vit.qkv"
             self._gemm(plan, P(xn), w[o + "qkv.w"], P(qkv), M, 3 * D, D, bias=P(w[o + "qkv.b"]),
                        a_rows=plain(D), c_rows=plain(3 * D), scale_cols=D, scale=qscale)
+            self._tag = "vit.attn"
             self._attn(plan, P(qkv), P(qkv) + 2 * D, P(qkv) + 4 * D, P(att), B, Hv, N, N,
                        3 * D, 3 * D, 3 * D, D, N * 3 * D, N * 3 * D, N * 3 * D, N * D)
+            self._tag = "vit.proj"
             self._gemm(plan, P(att), w[o + "proj.w"], P(x), M, D, D, bias=P(w[o + "proj.b"]), residual=P(x),
                        a_rows=plain(D), c_rows=plain(D), r_rows=plain(D), **rkw)
+            self._tag = "vit.ln"
             self._ln(plan, P(x), xf32, w[o + "ln2.g"], w[o + "ln2.b"], P(xn), None, M, D, cfg.vit_ln_eps)
+            self._tag = "vit.fc1_gelu"
             self._gemm(plan, P(xn), w[o + "fc1.w"], P(hid), M, D * cfg.mlp_ratio, D, bias=P(w[o + "fc1.b"]),
                        a_rows=plain(D), c_rows=plain(D * cfg.mlp_ratio), act=L.HK_ACT_GELU_ERF)
+            self._tag = "vit.fc2"
             self._gemm(plan, P(hid), w[o + "fc2.w"], P(x), M, D, D * cfg.mlp_ratio, bias=P(w[o + "fc2.b"]),
                        residual=P(x), a_rows=plain(D * cfg.mlp_ratio), c_rows=plain(D), r_rows=plain(D), **rkw)
         # vision_layernorm (hawkeye_it.py:234) then the K/V projections of every cross layer at once
+        self._tag = "vision_layernorm"
         self._ln(plan, P(x), xf32, w["vln.g"], w["vln.b"], P(xn), None, M, D, cfg.vision_ln_eps)
+        self._tag = "qformer.cross_kv"
         self._gemm(plan, P(xn), w["ckv.w"], P(kvc), M, KVW, D, bias=P(w["ckv.b"]), a_rows=plain(D), c_rows=plain(KVW))
 
         # ---- Q-Former ----
+        self._tag = "qformer"
         plan.steps.append((self.lib.hk_qformer_embed_ln,
                            (P(w["query"]), P(w["emb.word"]), P(w["emb.pos"]), P(ids) if Lt > 0 else None,
                             P(w["emb.ln.g"]), P(w["emb.ln.b"]), P(hf), P(hb), B, nq, Lt, d, w["emb.word"].shape[0],
-                            cfg.qf_ln_eps), "hk_qformer_embed_ln"))
+                            cfg.qf_ln_eps), "hk_qformer_embed_ln", "qformer"))
         qrows = (d, nq, S * d)
         trows = (d, Lt, S * d)
         eb = 2  # bytes per bf16
@@ -263,6 +275,7 @@ class HipEncoderEngine:
                 self._ln(plan, P(tf), True, w[o + "to.g"], w[o + "to.bt"], P(hb) + toff * eb, P(hf) + toff * 4,
                          B * Lt, d, cfg.qf_ln_eps, out_rows=trows)
         # llama_proj on the query rows (hawkeye_it.py:269)
+        self._tag = "llama_proj"
         self._gemm(plan, P(hb), w["proj.w"], P(out), B * nq, cfg.llama_hidden, d, bias=P(w["proj.b"]),
                    a_rows=qrows, c_rows=plain(cfg.llama_hidden), out_f32=True)
         return plan
@@ -270,21 +283,31 @@ class HipEncoderEngine:
     # ------------------------------------------------------------------ run
     @torch.no_grad()
     def forward(self, image: torch.Tensor, input_ids: Optional[torch.Tensor], text_mask: Optional[torch.Tensor],
-                pos_embed: torch.Tensor) -> torch.Tensor:
-        """image [B,T,3,H,W] fp32 on the engine's GPU; input_ids/text_mask [B,Lt] int64 (or None);
+                pos_embed: torch.Tensor, profile: Optional[list] = None, norm=None) -> torch.Tensor:
+        """image [B,T,3,H,W] fp32 on the engine's GPU, or decoded frames [B,T,H,W,3] uint8 (normalised on the
+        device with norm = (mean3, std3), default the CLIP statistics of the eval scripts); input_ids/text_mask [B,Lt] int64 (or None);
         pos_embed fp32 [N,D] on the GPU (the table the caller's encoder holds for this T).
         Returns fp32 [B, n_query, llama_hidden] -- a view of the plan's output buffer."""
         cfg = self.cfg
         if not self.w:
             raise RuntimeError("HipEncoderEngine: load_state_dict() has not been called")
-        if image.dim() != 5 or image.shape[2] != 3:
-            raise RuntimeError(f"image must be [B,T,3,H,W], got {tuple(image.shape)}")
-        B, T, _, H, W = image.shape
+        u8 = image.dtype == torch.uint8
+        if u8:
+            # row f3: decoded frames [B,T,H,W,3] uint8; /255, mean/std fused into the patch gather
+            if image.dim() != 5 or image.shape[4] != 3:
+                raise RuntimeError(f"uint8 frames must be [B,T,H,W,3], got {tuple(image.shape)}")
+            B, T, H, W, _ = image.shape
+        else:
+            if image.dim() != 5 or image.shape[2] != 3:
+                raise RuntimeError(f"image must be [B,T,3,H,W], got {tuple(image.shape)}")
+            B, T, _, H, W = image.shape
         if H != cfg.img_size or W != cfg.img_size:
             raise RuntimeError(f"image must be {cfg.img_size}x{cfg.img_size}, got {H}x{W}")
         if image.device != self.device:
             raise RuntimeError(f"image is on {image.device}, engine on {self.device}")
-        if image.dtype != torch.float32 or not image.is_contiguous():
+        if u8:
+            image = image.contiguous()
+        elif image.dtype != torch.float32 or not image.is_contiguous():
             image = image.float().contiguous()
         Lt = 0 if input_ids is None else int(input_ids.shape[1])
         N = T * cfg.patches_per_frame
@@ -308,14 +331,43 @@ class HipEncoderEngine:
                 kb[:, nq:].copy_((1.0 - text_mask.to(device=self.device, dtype=torch.float32)) * -10000.0)
             else:
                 ws["kbias"].zero_()
-            L.check(self.lib.hk_patchify_bf16(image.data_ptr(), ws["patches"].data_ptr(), B, T, H, W, cfg.patch_size,
-                                              stream), "hk_patchify_bf16")
+            if u8:
+                mean, std = norm if norm is not None else (ops.CLIP_MEAN, ops.CLIP_STD)
+                m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+                L.check(self.lib.hk_patchify_u8(image.data_ptr(), ws["patches"].data_ptr(), B, T, H, W, cfg.patch_size,
+                                                m3, s3, stream), "hk_patchify_u8")
+            else:
+                L.check(self.lib.hk_patchify_bf16(image.data_ptr(), ws["patches"].data_ptr(), B, T, H, W,
+                                                  cfg.patch_size, stream), "hk_patchify_bf16")
             plan.patch_desc.residual = pos_embed.data_ptr()
-            for fn, args, name in plan.steps:
-                rc = fn(*args, stream)
-                if rc != 0:
-                    L.check(rc, name)
+            if profile is None:
+                for fn, args, name, _ in plan.steps:
+                    rc = fn(*args, stream)
+                    if rc != 0:
+                        L.check(rc, name)
+            else:
+                # one HIP event pair per launch on the launch stream; resolved by profile()
+                for fn, args, name, tag in plan.steps:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    rc = fn(*args, stream)
+                    e1.record()
+                    if rc != 0:
+                        L.check(rc, name)
+                    profile.append((tag, e0, e1))
         return ws["out"].view(B, nq, cfg.llama_hidden)
+
+    def profile(self, image, input_ids, text_mask, pos_embed, reps: int = 3) -> Dict[str, Tuple[int, float]]:
+        """In-situ launch durations: {tag: (launches per call, mean us per launch)} from HIP events
+        recorded around every launch of `reps` forward calls (same stream, same order as forward)."""
+        acc: Dict[str, List[float]] = {}
+        for _ in range(reps):
+            rec: List = []
+            self.forward(image, input_ids, text_mask, pos_embed, profile=rec)
+            torch.cuda.synchronize(self.device)
+            for tag, e0, e1 in rec:
+                acc.setdefault(tag, []).append(e0.elapsed_time(e1) * 1e3)
+        return {t: (len(v) // reps, sum(v) / len(v)) for t, v in acc.items()}
 
     def workspace_bytes(self, B: int, T: int, Lt: int) -> int:
         plan = self.plans.get((B, T, Lt))

@@ -50,10 +50,14 @@ SYMBOLS = {
                                C.POINTER(HkRows), C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
     "hk_patchify_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_void_p]),
+    "hk_patchify_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                 C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p]),
+    "hk_pos_embed": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "hk_qformer_embed_ln": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                       C.c_float, C.c_void_p]),
     "hk_cast_f32_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "hk_mfma_probe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "hk_version": (C.c_int, []),
     "hk_arch": (C.c_char_p, []),
     "hk_last_error": (C.c_size_t, [C.c_char_p, C.c_size_t]),

@@ -25,7 +25,7 @@ from typing import Optional, Sequence, Tuple, Union
 import torch
 import torch.nn as nn
 
-from . import posembed
+from . import ops, posembed
 from .config import EncoderConfig
 from .engine import HipEncoderEngine
 
@@ -205,6 +205,9 @@ class HawkEyeEncoder(nn.Module):
         self._engine: Optional[HipEncoderEngine] = None
         self._engine_key = None
         self._table_cache = {}
+        # row f4: True = ignore the pos_embed attributes and generate the sinusoid table for the clip's frame
+        # count on the device (cached per T); False (default) = the reference contract, read the attribute
+        self.device_pos_embed = False
 
     # ---- reference module protocol -------------------------------------------------
     @property
@@ -251,6 +254,15 @@ class HawkEyeEncoder(nn.Module):
 
     def _table(self, use_image: bool, n_tokens: int, dev) -> torch.Tensor:
         enc = self.vision_encoder.encoder
+        if self.device_pos_embed:
+            key = ("dev", use_image, n_tokens, str(dev))
+            hit = self._table_cache.get(key)
+            if hit is None:
+                Lp = self.cfg.patches_per_frame
+                hit = ops.pos_embed(n_tokens // Lp, Lp, self.cfg.encoder_embed_dim,
+                                    -1 if use_image else self.cfg.ckpt_num_frame, dev)
+                self._table_cache[key] = hit
+            return hit
         t = enc.img_pos_embed if use_image else enc.pos_embed     # read at call time (vit.py:304-307)
         if t.shape[-2] != n_tokens:
             raise RuntimeError(
@@ -284,6 +296,18 @@ class HawkEyeEncoder(nn.Module):
     @torch.no_grad()
     def encode_img(self, image: torch.Tensor, instruction: Union[str, Sequence[str], Tuple[torch.Tensor, torch.Tensor]]):
         """hawkeye_it.py:219-270.  image [B,T,3,H,W] float on the model's GPU."""
+        return self._encode(image, instruction, None)
+
+    @torch.no_grad()
+    def encode_frames(self, frames: torch.Tensor, instruction, mean=ops.CLIP_MEAN, std=ops.CLIP_STD):
+        """Row f3: encode_img on decoded frames.  frames [B,T,H,W,3] uint8 (resized + centre-cropped, as
+        decord/PIL produce them, tasks/test_recursive_grounding.py:364-385) on the model's GPU; the /255 and
+        mean/std steps of the eval transform (:333-343) run inside the patch gather.  Same return as encode_img."""
+        if frames.dtype != torch.uint8:
+            raise RuntimeError(f"encode_frames expects uint8 frames, got {frames.dtype}")
+        return self._encode(frames, instruction, (tuple(mean), tuple(std)))
+
+    def _encode(self, image, instruction, norm):
         device = image.device
         eng = self.sync_engine()
         if device != eng.device:
@@ -294,6 +318,6 @@ class HawkEyeEncoder(nn.Module):
         ids = mask = None
         if self.qformer_text_input:
             ids, mask = self._tokenize(instruction, B, eng.device)
-        out = eng.forward(image, ids, mask, table)
+        out = eng.forward(image, ids, mask, table, norm=norm)
         out = out.to(self.out_dtype) if self.out_dtype != torch.float32 else out.clone()
         return out.to(device), use_image

@@ -158,6 +158,34 @@ def patchify(clip: torch.Tensor, patch: int, out: Optional[torch.Tensor] = None)
     return out
 
 
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)   # tasks/test_recursive_grounding.py:333-334
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def patchify_u8(frames: torch.Tensor, patch: int, mean=CLIP_MEAN, std=CLIP_STD,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """frames [B,T,H,W,3] uint8 contiguous -> normalised [B*T*(H/p)*(W/p), 3*p*p] bf16 (row f3)."""
+    _need(frames, torch.uint8, "frames")
+    if frames.dim() != 5 or frames.shape[4] != 3 or not frames.is_contiguous():
+        raise RuntimeError("patchify_u8: frames must be contiguous [B,T,H,W,3]")
+    B, T, H, W, _ = frames.shape
+    rows = B * T * (H // patch) * (W // patch)
+    if out is None:
+        out = torch.empty((rows, 3 * patch * patch), dtype=torch.bfloat16, device=frames.device)
+    m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+    L.check(L.load().hk_patchify_u8(frames.data_ptr(), out.data_ptr(), B, T, H, W, patch, m3, s3, _stream()),
+            "hk_patchify_u8")
+    return out
+
+
+def pos_embed(T: int, Lp: int, D: int, ckpt_frames: int, device) -> torch.Tensor:
+    """fp32 [T*Lp, D] sinusoid table generated on the device (row f4); ckpt_frames <= 0 = no interpolation."""
+    out = torch.empty((T * Lp, D), dtype=torch.float32, device=device)
+    with torch.cuda.device(out.device):
+        L.check(L.load().hk_pos_embed(out.data_ptr(), T, Lp, D, ckpt_frames, _stream()), "hk_pos_embed")
+    return out
+
+
 def qformer_embed_ln(query_tokens, word_emb, pos_emb, input_ids, gamma, beta, eps, out_f32, out_bf16):
     """query_tokens [nq,d], word_emb [V,d], pos_emb [P,d] fp32; input_ids [B,Lt] int64 (or None)."""
     nq, d = query_tokens.shape
@@ -181,3 +209,23 @@ def cast_bf16(x: torch.Tensor) -> torch.Tensor:
     out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
     L.check(L.load().hk_cast_f32_bf16(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "hk_cast_f32_bf16")
     return out
+
+
+def mfma_probe_tflops(kind: int = 0, *, zeros: bool = False, grid: int = 2048, iters: int = 4000, reps: int = 5) -> float:
+    """Measured dense-bf16 MFMA rate of this chip (register-resident probe, include/hawkeye_hip.h hk_mfma_probe).
+    zeros=True feeds all-zero operands (lowest switching power, highest sustained clock)."""
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(7)
+    seed = (torch.zeros(2048) if zeros else torch.randn(2048, generator=g)).to(torch.bfloat16).to(dev)
+    out = torch.empty(grid * 256, dtype=torch.float32, device=dev)
+    lib = L.load()
+    st = _stream()
+    L.check(lib.hk_mfma_probe(seed.data_ptr(), out.data_ptr(), grid, iters // 10, kind, st), "hk_mfma_probe")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        L.check(lib.hk_mfma_probe(seed.data_ptr(), out.data_ptr(), grid, iters, kind, st), "hk_mfma_probe")
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    return grid * iters * 524288.0 / (ms * 1e-3) / 1e12

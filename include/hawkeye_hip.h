@@ -110,6 +110,19 @@ int hk_layernorm(const void* x, int32_t in_dtype, const float* add, const float*
 int hk_patchify_bf16(const float* clip, void* out, int32_t B, int32_t T, int32_t H, int32_t W, int32_t patch,
                      void* stream);
 
+/* Row f3: the eval pipeline's frame transform fused into the patch gather.  frames uint8 [B,T,H,W,3] (decoded,
+ * resized and cropped frames as decord/PIL hand them over, dataset/video_utils.py:154-176) ->
+ * ((x / 255) - mean[c]) / std[c] in fp32, each step rounded as the reference's ToTorchFormatTensor
+ * (dataset/video_transforms.py:367-389) and GroupNormalize (:94-107) round it -> the same bf16 [rows, 3*p*p]
+ * operand hk_patchify_bf16 produces from the normalised fp32 clip.  mean3/std3 are HOST pointers to 3 floats. */
+int hk_patchify_u8(const uint8_t* frames, void* out, int32_t B, int32_t T, int32_t H, int32_t W, int32_t patch,
+                   const float* mean3, const float* std3, void* stream);
+
+/* Row f4: fixed sinusoid position table on the device, fp32 [T*L, D].  get_sinusoid_encoding_table
+ * (models/blip2/vit.py:163-194): float64 angles, sin/cos, cast to fp32; if ckpt_frames > 0 and != T the
+ * [ckpt_frames, L, D] table is linearly interpolated along the frame axis (align_corners=False, vit.py:186). */
+int hk_pos_embed(float* out, int32_t T, int32_t L, int32_t D, int32_t ckpt_frames, void* stream);
+
 /* Q-Former embeddings: rows [0,nq) = query_tokens; rows [nq, nq+Lt) = word_emb[ids] + pos_emb[0..Lt);
  * LayerNorm(eps) -> out_f32 and out_bf16 [B, nq+Lt, d].  (Qformer.py:97-121; hawkeye_it.py:237-241) */
 int hk_qformer_embed_ln(const float* query_tokens, const float* word_emb, const float* pos_emb,
@@ -119,6 +132,12 @@ int hk_qformer_embed_ln(const float* query_tokens, const float* word_emb, const 
 
 /* fp32 -> bf16 (round-to-nearest-even) copy of n elements; weight packing at load time. */
 int hk_cast_f32_bf16(const float* x, void* out, int64_t n, void* stream);
+
+/* Measurement aid, no reference counterpart (SURVEY.md §8d asks for a register-resident MFMA-peak probe):
+ * `grid` workgroups of 4 waves each issue `iters` x 8 independent v_mfma_f32_16x16x32_bf16 (kind 0) or
+ * `iters` x 4 v_mfma_f32_32x32x16_bf16 (kind 1) on fragments loaded once from seed_bf16_2048 (2048 bf16 values);
+ * one launch = grid * iters * 524288 flops.  out: fp32 [grid * 256]. */
+int hk_mfma_probe(const void* seed_bf16_2048, float* out, int32_t grid, int32_t iters, int32_t kind, void* stream);
 
 /* Library identification and last-error text. */
 int hk_version(void);

@@ -23,6 +23,22 @@ import torch.nn.functional as F
 
 
 # ----------------------------------------------------------------------------
+# Frame transform feeding the path (row f3)
+# ----------------------------------------------------------------------------
+
+def normalize_frames(frames_u8, mean, std):
+    """uint8 frames [B,T,H,W,3] -> the fp32 clip [B,T,3,H,W] the eval scripts hand to encode_img.
+
+    dataset/video_transforms.py:367-389 ToTorchFormatTensor (HWC -> CHW, .float().div(255)) and :94-107
+    GroupNormalize (per channel t.sub_(mean).div_(std), fp32 tensor with Python-float scalars), then the caller's
+    reshape to [1,T,3,H,W] (tasks/test.py:490-492).  Pinned by tests/golden/frame_transform.npz."""
+    x = frames_u8.permute(0, 1, 4, 2, 3).contiguous().float().div(255)
+    for c in range(3):
+        x[:, :, c].sub_(float(mean[c])).div_(float(std[c]))
+    return x
+
+
+# ----------------------------------------------------------------------------
 # ViT  (models/blip2/vit.py)
 # ----------------------------------------------------------------------------
 

@@ -15,10 +15,15 @@ all in memory, none touching the reference checkout:
      find_pruneable_heads_and_indices, prune_linear_layer.
   3. BertPreTrainedModel.init_weights -> self.apply(self._init_weights).
   4. BertModel.get_head_mask (removed) -> [None] * n.
+  5. (frame-transform fixture only) `torchvision` is absent: an empty stub module lets
+     dataset/video_transforms.py import; the classes used here (Stack, ToTorchFormatTensor,
+     GroupNormalize) never touch it.  GroupScale / GroupCenterCrop (which do) are not used: the
+     fixture's frames are generated at the final resolution.
 
 Usage:  python oracle/make_goldens.py            (writes tests/golden/)
 """
 import importlib.machinery
+import importlib.util
 import os
 import sys
 import types
@@ -233,12 +238,48 @@ def pos_embed_goldens(ref_vit, outdir):
     print("wrote pos_embed.npz")
 
 
+def frame_transform_goldens(outdir):
+    """Row f3 fixture: the eval transform tail (tasks/test_recursive_grounding.py:335-343 minus the resize/crop)
+    on uint8 frames, then the caller's reshape to [1,T,3,H,W] (tasks/test.py:490-492)."""
+    if "torchvision" not in sys.modules:
+        tv = types.ModuleType("torchvision")
+        tv.__spec__ = importlib.machinery.ModuleSpec("torchvision", None)
+        sys.modules["torchvision"] = tv
+    from PIL import Image
+    # the module file alone: the package __init__ pulls in decord / torchvision.transforms, which are absent
+    spec = importlib.util.spec_from_file_location("ref_video_transforms",
+                                                  os.path.join(REF, "dataset", "video_transforms.py"))
+    vt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(vt)
+    mean = [0.48145466, 0.4578275, 0.40821073]
+    std = [0.26862954, 0.26130258, 0.27577711]
+    rng = np.random.Generator(np.random.PCG64(11))
+    T, H, W = 3, 64, 64
+    frames = rng.integers(0, 256, size=(T, H, W, 3), dtype=np.uint8)
+    frames[0, 0, :8] = 0          # extremes of the range in every channel
+    frames[0, 1, :8] = 255
+    frames[1, 0, :256 // 4, 0] = np.arange(0, 256, 4, dtype=np.uint8)
+    tf = [vt.Stack(), vt.ToTorchFormatTensor(), vt.GroupNormalize(mean, std)]
+    x = [Image.fromarray(f) for f in frames]
+    for f in tf:
+        x = f(x)
+    TC, Hh, Ww = x.shape
+    video = x.reshape(1, TC // 3, 3, Hh, Ww)
+    np.savez_compressed(os.path.join(outdir, "frame_transform.npz"), frames=frames, video=video.numpy(),
+                        mean=np.array(mean, dtype=np.float64), std=np.array(std, dtype=np.float64))
+    print("wrote frame_transform.npz", tuple(video.shape))
+
+
 def main():
     torch.manual_seed(0)
     outdir = os.path.join(REPO, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
+    if sys.argv[1:] == ["frames"]:
+        frame_transform_goldens(outdir)
+        return
     ref_vit, ref_qf = _import_reference()
     pos_embed_goldens(ref_vit, outdir)
+    frame_transform_goldens(outdir)
     # reduced shape: every stage tensor in full
     run_case("small_video", SMALL, B=2, T=2, Lt=6, seed=3, ragged=True, full_tensors=True,
              ref_vit=ref_vit, ref_qf=ref_qf, outdir=outdir)

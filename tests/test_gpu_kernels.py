@@ -98,6 +98,37 @@ def test_gemm_bf16_residual_in_place(M, N, K):
     assert _rel(o32, x.float() @ w.float().t() + b + res.float()) < 2e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(256 * 552 + 37, 256, 128), (100352, 1024, 256), (256 * 140, 1024, 64)])
+def test_gemm_split_tail_rows_match_a_plain_launch(M, N, K):
+    """Tile counts with a small last round (552 = 2*256 + 40; 1568 = 6*256 + 32; 560 = 2*256 + 48) take the
+    two-launch path (persistent kernel over whole rounds + multi-stage kernel over the tail rows): every
+    output row is written exactly once, with the same epilogue, including row maps and the in-place residual."""
+    x = _rand((M, K), 31, dtype=torch.bfloat16)
+    w = _rand((N, K), 32, 0.05, dtype=torch.bfloat16)
+    b = _rand((N,), 33)
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.linear(x, w, b, act="gelu", out=out)
+    ref = torch.nn.functional.gelu(x.float() @ w.float().t() + b)
+    assert not torch.isnan(out).any()
+    assert _rel(out.float(), ref) < 6e-3
+    del ref
+    # in-place bf16 residual stream + broadcast-free row map (rows_per_batch) across the split point
+    res = _rand((M, N), 34, dtype=torch.bfloat16)
+    want = (x.float() @ w.float().t() + b + res.float())
+    ops.linear(x, w, b, residual=res, out=res)
+    assert _rel(res.float(), want) < 6e-3
+    rpb = 1000
+    nb = M // rpb
+    Mm = nb * rpb
+    big = torch.zeros((nb, rpb + 8, N), dtype=torch.float32, device=DEV)
+    d = ops.gemm_desc(x.data_ptr(), w.data_ptr(), big.data_ptr(), Mm, N, K, bias=b.data_ptr(),
+                      a_rows=(K, 0, 0), c_rows=(N, rpb, (rpb + 8) * N), out_f32=True)
+    ops.run_gemm(d)
+    ref3 = (x[:Mm].float() @ w.float().t() + b).view(nb, rpb, N)
+    assert _rel(big[:, :rpb], ref3) < 2e-5
+    assert torch.count_nonzero(big[:, rpb:]) == 0
+
+
 def test_gemm_rejects_bad_shapes():
     x = _rand((8, 48), 1, dtype=torch.bfloat16)
     w = _rand((16, 48), 2, dtype=torch.bfloat16)
@@ -204,6 +235,46 @@ def test_patchify_is_an_exact_gather():
     out = ops.patchify(clip, P)
     ref = clip.view(B, T, 3, H // P, P, W // P, P).permute(0, 1, 3, 5, 2, 4, 6).reshape(-1, 3 * P * P)
     assert torch.equal(out, ref.to(torch.bfloat16))
+
+
+def test_patchify_u8_is_the_reference_transform_bit_for_bit(golden_dir):
+    """Row f3: uint8 frames -> ((x/255) - mean)/std -> bf16 patches must equal the fp32 patch gather of the clip the
+    reference's transform classes produce (tests/golden/frame_transform.npz), and of a larger random clip
+    normalised with the same separately rounded fp32 steps."""
+    import os
+    import numpy as np
+    g = np.load(os.path.join(golden_dir, "frame_transform.npz"))
+    frames = torch.from_numpy(g["frames"]).unsqueeze(0).to(DEV)            # [1,T,H,W,3]
+    video = torch.from_numpy(g["video"]).to(DEV)                           # [1,T,3,H,W] by the reference classes
+    got = ops.patchify_u8(frames, 16, g["mean"].tolist(), g["std"].tolist())
+    assert torch.equal(got, ops.patchify(video.contiguous(), 16))
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    fr = torch.randint(0, 256, (2, 3, 224, 224, 3), generator=gen, dtype=torch.uint8).to(DEV)
+    x = fr.permute(0, 1, 4, 2, 3).contiguous().float().div(255)
+    for c in range(3):
+        x[:, :, c].sub_(ops.CLIP_MEAN[c]).div_(ops.CLIP_STD[c])
+    assert torch.equal(ops.patchify_u8(fr, 16), ops.patchify(x, 16))
+
+
+@pytest.mark.parametrize("T", [1, 4, 8, 12, 16])
+def test_pos_embed_on_device_matches_reference_table(golden_dir, T):
+    """Row f4: the device-generated table vs rows of the reference's get_sinusoid_encoding_table
+    (tests/golden/pos_embed.npz) and vs the host restatement.  The angle is float64 on both sides; libm and the
+    device math library may differ in the last float64 bit, which after the cast shows as an occasional 1-ulp
+    fp32 difference: tolerance 1.2e-7 absolute (values are in [-1, 1]), and < 0.1 % of elements may differ at all."""
+    import os
+    import numpy as np
+    from hawkeye_amd import posembed
+    g = np.load(os.path.join(golden_dir, "pos_embed.npz"))
+    tab = ops.pos_embed(T, 196, 1024, -1 if T == 1 else 4, DEV)
+    rows = torch.from_numpy(g[f"T{T}.rows"]).to(DEV)
+    ref_rows = torch.from_numpy(g[f"T{T}.vals"]).to(DEV)
+    assert (tab[rows] - ref_rows).abs().max().item() <= 1.2e-7
+    host = (posembed.image_pos_embed(196, 1024) if T == 1 else posembed.video_pos_embed(T, 196, 1024, 4)).reshape(-1, 1024)
+    diff = (tab.cpu() - host)
+    assert diff.abs().max().item() <= 1.2e-7
+    assert (diff != 0).float().mean().item() < 1e-3
+    assert abs(tab.double().norm().item() - float(g[f"T{T}.l2"])) < 1e-3
 
 
 def test_qformer_embed_ln():

@@ -119,6 +119,36 @@ def test_against_oracle_same_seed_ragged_batch():
     assert _cos(out_b1[0], out[1]) > 0.99999
 
 
+def test_encode_frames_uint8_input_and_device_pos_embed(golden_dir):
+    """Rows f3 + f4 end to end: uint8 frames normalised inside the patch gather and the position table generated
+    on the device, against the oracle fed the clip the reference transform produces and the host table."""
+    from oracle import encode_img_oracle as O
+    cfg, seed, B, T, Lt = SMALL, 21, 2, 3, 5
+    sd = W.make_state_dict(cfg, seed)
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    frames = torch.randint(0, 256, (B, T, cfg.img_size, cfg.img_size, 3), generator=gen, dtype=torch.uint8)
+    mean, std = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)
+    image = O.normalize_frames(frames, mean, std)
+    ids, mask = W.make_instruction_ids(B, Lt, cfg.qf_vocab, seed, ragged=True)
+    table = posembed.video_pos_embed(T, cfg.patches_per_frame, cfg.encoder_embed_dim, cfg.ckpt_num_frame)
+    with torch.no_grad():
+        ref, _ = O.encode_img(sd, cfg.to_dict(), image, ids, mask, table)
+    m = HawkEyeEncoder(cfg, out_dtype=torch.float32)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV)
+    m.device_pos_embed = True                 # the pos_embed attribute (built for cfg.num_frames) is not read
+    out, use_image = m.encode_frames(frames.to(DEV), (ids, mask))
+    assert not use_image
+    _check("frames_u8_small", out, ref.numpy())
+    # same bits as the fp32-clip entry with the host table (transform and table are exact restatements)
+    m.device_pos_embed = False
+    m.vision_encoder.encoder.pos_embed = table
+    out2, _ = m.encode_img(image.to(DEV), (ids, mask))
+    assert _cos(out, out2) > 0.999999
+    with pytest.raises(RuntimeError, match="uint8"):
+        m.encode_frames(image.to(DEV), (ids, mask))
+
+
 def test_default_output_dtype_and_errors():
     m = HawkEyeEncoder(SMALL)
     m.load_state_dict(W.make_state_dict(SMALL, 1), strict=True)
