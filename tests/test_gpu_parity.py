@@ -149,6 +149,28 @@ def test_encode_frames_uint8_input_and_device_pos_embed(golden_dir):
         m.encode_frames(image.to(DEV), (ids, mask))
 
 
+def test_packed_operand_file_round_trip(tmp_path):
+    """Row f4: the packed safetensors operand set reproduces the engine bit for bit in a model that never saw
+    the fp32 weights."""
+    from hawkeye_amd import checkpoint as CK
+    cfg, seed = SMALL, 9
+    sd = W.make_state_dict(cfg, seed)
+    image = W.make_clip(2, 2, cfg.img_size, seed).to(DEV)
+    ids, mask = W.make_instruction_ids(2, 4, cfg.qf_vocab, seed)
+    m = _model(cfg, seed, 2)
+    want, _ = m.encode_img(image, (ids, mask))
+    path = str(tmp_path / "packed.safetensors")
+    assert CK.save_packed(m, path) > 0
+    fresh = HawkEyeEncoder(cfg, out_dtype=m.out_dtype).to(DEV)       # random initial weights
+    fresh.vision_encoder.encoder.pos_embed = m.vision_encoder.encoder.pos_embed
+    CK.load_packed(fresh, path)
+    got, _ = fresh.encode_img(image, (ids, mask))
+    assert torch.equal(got, want)
+    other = HawkEyeEncoder(FULL).to(DEV)
+    with pytest.raises(RuntimeError, match="different EncoderConfig"):
+        CK.load_packed(other, path)
+
+
 def test_default_output_dtype_and_errors():
     m = HawkEyeEncoder(SMALL)
     m.load_state_dict(W.make_state_dict(SMALL, 1), strict=True)
