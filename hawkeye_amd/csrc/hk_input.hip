@@ -81,7 +81,30 @@ __global__ __launch_bounds__(256) void hk_pos_embed_kernel(float* __restrict__ o
     out[i] = __fmaf_rn(l0, v0, __fmul_rn(l1, v1));
 }
 
+// Qformer.py:746-835 get_extended_attention_mask on cat(ones[B,nq], text_mask[B,Lt]) (hawkeye_it.py:250):
+// additive key bias (1 - m) * -10000, fp32 [B, nq + Lt]; query columns are never masked.
+__global__ __launch_bounds__(256) void hk_key_bias_kernel(const int64_t* __restrict__ mask, float* __restrict__ out,
+                                                          int B, int nq, int Lt) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int S = nq + Lt;
+    if (i >= B * S) return;
+    const int b = i / S, s = i - b * S;
+    out[i] = s < nq ? 0.f : (1.0f - (float)mask[(int64_t)b * Lt + (s - nq)]) * -10000.0f;
+}
+
 }  // namespace
+
+extern "C" int hk_qformer_key_bias(const int64_t* text_mask, float* out, int32_t B, int32_t nq, int32_t Lt,
+                                   void* stream) {
+    HK_REQUIRE(out != nullptr && (Lt == 0 || text_mask != nullptr), "hk_qformer_key_bias: null pointer");
+    HK_REQUIRE(B > 0 && nq >= 0 && Lt >= 0 && nq + Lt > 0 && (int64_t)B * (nq + Lt) < (1L << 31),
+               "hk_qformer_key_bias: bad shape B=%d nq=%d Lt=%d", B, nq, Lt);
+    const int n = B * (nq + Lt);
+    hipLaunchKernelGGL(hk_key_bias_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       text_mask, out, B, nq, Lt);
+    HK_CHECK_LAUNCH("hk_qformer_key_bias");
+    return HK_OK;
+}
 
 extern "C" int hk_patchify_u8(const uint8_t* frames, void* out, int32_t B, int32_t T, int32_t H, int32_t W,
                               int32_t patch, const float* mean3, const float* std3, void* stream) {

@@ -19,6 +19,7 @@ Data layout in HBM (row-major, M = B*N image tokens, N = T*L):
 """
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -36,6 +37,7 @@ class _Plan:
         self.steps: List[Tuple] = []       # (fn, args) ; stream appended at run time
         self.keep: List = []               # descriptors / ctypes objects kept alive
         self.patch_desc: Optional[L.HkGemmDesc] = None
+        self.graphs: Dict[Tuple, "torch.cuda.CUDAGraph"] = {}   # captured calls, keyed by (input kind, table, norm)
 
     def buf(self, name, shape, dtype, device):
         t = torch.empty(shape, dtype=dtype, device=device)
@@ -63,6 +65,13 @@ class HipEncoderEngine:
         self.plans: Dict[Tuple[int, int, int], _Plan] = {}
         self.n_cross = len([i for i in range(cfg.qf_layers) if i % cfg.cross_attention_freq == 0])
         self._tag = ""          # label of the plan steps being appended (profile() groups by it)
+        # Optional hipGraph replay of a whole call for small sizes (HK_GRAPH=1, limit HK_GRAPH_MAX_FRAMES).  Off by
+        # default: measured on MI355X it changes nothing (B=1,T=12: 6.22 vs 6.24 ms) -- the floor of a small call
+        # is the ~300-600 DEPENDENT kernels' own dispatch-to-completion latency, which a graph does not shorten;
+        # the host-side enqueue it removes was already hidden behind the GPU.  Kept for callers that want the
+        # host thread free.
+        self.use_graphs = os.environ.get("HK_GRAPH", "0") == "1"
+        self.graph_max_frames = int(os.environ.get("HK_GRAPH_MAX_FRAMES", "64"))
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):
@@ -174,6 +183,7 @@ class HipEncoderEngine:
             kvc = plan.buf("kvc", (M, KVW), bf16, dev)
             ids = plan.buf("ids", (B, max(Lt, 1)), torch.int64, dev)
             kbias = plan.buf("kbias", (B, S), f32, dev)
+            plan.buf("mask", (B, max(Lt, 1)), torch.int64, dev)
             hf = plan.buf("hf", (B * S, d), f32, dev)
             hb = plan.buf("hb", (B * S, d), bf16, dev)
             qqkv = plan.buf("qqkv", (B * S, 3 * d), bf16, dev)
@@ -322,40 +332,65 @@ class HipEncoderEngine:
         ws = plan.ws
         nq = cfg.n_query
         with torch.cuda.device(self.device):
-            stream = torch.cuda.current_stream().cuda_stream
             if Lt > 0:
                 ws["ids"].copy_(input_ids, non_blocking=True)
-                kb = ws["kbias"]
-                kb[:, :nq].zero_()
-                # (1 - mask) * -10000 (Qformer.py:834); query columns are never masked (hawkeye_it.py:250)
-                kb[:, nq:].copy_((1.0 - text_mask.to(device=self.device, dtype=torch.float32)) * -10000.0)
+                ws["mask"].copy_(text_mask, non_blocking=True)
+            use_graph = profile is None and self.use_graphs and B * T <= self.graph_max_frames
+            if use_graph:
+                # Launch-bound sizes (a B=1 call is ~600 launches of a few microseconds each): the whole call is
+                # one hipGraph replay reading a fixed input buffer.  First call of a (plan, table, input kind):
+                # one eager pass (per-kernel static set-up happens there), then capture.
+                name = "in_u8" if u8 else "in_f32"
+                if name not in ws:
+                    plan.buf(name, tuple(image.shape), image.dtype, self.device)
+                ws[name].copy_(image, non_blocking=True)
+                gkey = (name, pos_embed.data_ptr(), norm)
+                g = plan.graphs.get(gkey)
+                if g is None:
+                    self._enqueue(plan, ws[name], u8, norm, pos_embed, B, T, Lt, H, W, None)
+                    torch.cuda.current_stream().synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self._enqueue(plan, ws[name], u8, norm, pos_embed, B, T, Lt, H, W, None)
+                    if len(plan.graphs) >= 4:      # e.g. a caller that assigns a fresh pos_embed tensor per call
+                        plan.graphs.pop(next(iter(plan.graphs)))
+                    plan.graphs[gkey] = g
+                    plan.keep.append(pos_embed)    # the captured launches read this table's address
+                g.replay()
             else:
-                ws["kbias"].zero_()
-            if u8:
-                mean, std = norm if norm is not None else (ops.CLIP_MEAN, ops.CLIP_STD)
-                m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
-                L.check(self.lib.hk_patchify_u8(image.data_ptr(), ws["patches"].data_ptr(), B, T, H, W, cfg.patch_size,
-                                                m3, s3, stream), "hk_patchify_u8")
-            else:
-                L.check(self.lib.hk_patchify_bf16(image.data_ptr(), ws["patches"].data_ptr(), B, T, H, W,
-                                                  cfg.patch_size, stream), "hk_patchify_bf16")
-            plan.patch_desc.residual = pos_embed.data_ptr()
-            if profile is None:
-                for fn, args, name, _ in plan.steps:
-                    rc = fn(*args, stream)
-                    if rc != 0:
-                        L.check(rc, name)
-            else:
-                # one HIP event pair per launch on the launch stream; resolved by profile()
-                for fn, args, name, tag in plan.steps:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    rc = fn(*args, stream)
-                    e1.record()
-                    if rc != 0:
-                        L.check(rc, name)
-                    profile.append((tag, e0, e1))
+                self._enqueue(plan, image, u8, norm, pos_embed, B, T, Lt, H, W, profile)
         return ws["out"].view(B, nq, cfg.llama_hidden)
+
+    def _enqueue(self, plan, image, u8, norm, pos_embed, B, T, Lt, H, W, profile):
+        """Every launch of one call, in order, on torch's current stream (also the body of the captured graph)."""
+        cfg, ws = self.cfg, plan.ws
+        stream = torch.cuda.current_stream().cuda_stream
+        L.check(self.lib.hk_qformer_key_bias(ws["mask"].data_ptr() if Lt > 0 else None, ws["kbias"].data_ptr(), B,
+                                             cfg.n_query, Lt, stream), "hk_qformer_key_bias")
+        if u8:
+            mean, std = norm if norm is not None else (ops.CLIP_MEAN, ops.CLIP_STD)
+            m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+            L.check(self.lib.hk_patchify_u8(image.data_ptr(), ws["patches"].data_ptr(), B, T, H, W, cfg.patch_size,
+                                            m3, s3, stream), "hk_patchify_u8")
+        else:
+            L.check(self.lib.hk_patchify_bf16(image.data_ptr(), ws["patches"].data_ptr(), B, T, H, W,
+                                              cfg.patch_size, stream), "hk_patchify_bf16")
+        plan.patch_desc.residual = pos_embed.data_ptr()
+        if profile is None:
+            for fn, args, name, _ in plan.steps:
+                rc = fn(*args, stream)
+                if rc != 0:
+                    L.check(rc, name)
+        else:
+            # one HIP event pair per launch on the launch stream; resolved by profile()
+            for fn, args, name, tag in plan.steps:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = fn(*args, stream)
+                e1.record()
+                if rc != 0:
+                    L.check(rc, name)
+                profile.append((tag, e0, e1))
 
     def profile(self, image, input_ids, text_mask, pos_embed, reps: int = 3) -> Dict[str, Tuple[int, float]]:
         """In-situ launch durations: {tag: (launches per call, mean us per launch)} from HIP events

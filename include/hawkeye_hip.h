@@ -130,6 +130,11 @@ int hk_qformer_embed_ln(const float* query_tokens, const float* word_emb, const 
                         void* out_bf16, int32_t B, int32_t nq, int32_t Lt, int32_t d, int32_t vocab, float eps,
                         void* stream);
 
+/* Additive key bias of the Q-Former self-attention: out fp32 [B, nq+Lt]; columns [0,nq) = 0 (queries are never
+ * masked, hawkeye_it.py:250), column nq+j = (1 - text_mask[b,j]) * -10000 (get_extended_attention_mask,
+ * Qformer.py:746-835).  text_mask int64 [B,Lt] (NULL when Lt == 0).  Feeds hk_flash_attn_bf16's key_bias. */
+int hk_qformer_key_bias(const int64_t* text_mask, float* out, int32_t B, int32_t nq, int32_t Lt, void* stream);
+
 /* fp32 -> bf16 (round-to-nearest-even) copy of n elements; weight packing at load time. */
 int hk_cast_f32_bf16(const float* x, void* out, int64_t n, void* stream);
 

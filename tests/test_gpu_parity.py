@@ -149,6 +149,31 @@ def test_encode_frames_uint8_input_and_device_pos_embed(golden_dir):
         m.encode_frames(image.to(DEV), (ids, mask))
 
 
+def test_graph_replay_is_bit_identical_to_eager_launches():
+    """Optional hipGraph replay of a whole call (engine.use_graphs): same bits as the eager launch loop, across
+    changing inputs, masks and a swapped position table."""
+    cfg, seed = SMALL, 13
+    m = _model(cfg, seed, 2)
+    eng = m.sync_engine()
+    outs = {}
+    for mode in (False, True):
+        eng.use_graphs = mode
+        res = []
+        for k in range(3):
+            image = W.make_clip(2, 2, cfg.img_size, seed + k).to(DEV)
+            ids, mask = W.make_instruction_ids(2, 6, cfg.qf_vocab, seed + k, ragged=True)
+            if k == 2:   # a caller that assigns a new table (demo.ipynb cell 6): new address, new capture
+                m.vision_encoder.encoder.pos_embed = m.vision_encoder.encoder.pos_embed.clone() * 0.5
+            res.append(m.encode_img(image, (ids, mask))[0].clone())
+        outs[mode] = res
+        m.vision_encoder.encoder.pos_embed = posembed.video_pos_embed(
+            2, cfg.patches_per_frame, cfg.encoder_embed_dim, cfg.ckpt_num_frame)
+    assert eng.plans[(2, 2, 6)].graphs, "graph mode did not capture"
+    for a, b in zip(outs[False], outs[True]):
+        assert torch.equal(a, b)
+    assert not torch.equal(outs[True][0], outs[True][1])
+
+
 def test_packed_operand_file_round_trip(tmp_path):
     """Row f4: the packed safetensors operand set reproduces the engine bit for bit in a model that never saw
     the fp32 weights."""

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""B=1 call latency (the recursive-grounding shape) with and without hipGraph replay (HK_GRAPH=0/1)."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hawkeye_amd import weights as W
+from hawkeye_amd.config import FULL
+from hawkeye_amd.model import HawkEyeEncoder
+DEV = torch.device("cuda", 0)
+cfg = FULL
+model = HawkEyeEncoder(cfg, out_dtype=torch.bfloat16)
+model.load_state_dict(W.make_state_dict(cfg, 1), strict=True)
+model = model.to(DEV).eval()
+model.device_pos_embed = True
+for B, T in ((1, 1), (1, 8), (1, 12), (1, 16), (4, 12), (4, 16)):
+    image = W.make_clip(B, T, cfg.img_size, 7).to(DEV)
+    ids, mask = W.make_instruction_ids(B, 32, cfg.qf_vocab, 7)
+    ids, mask = ids.to(DEV), mask.to(DEV)
+    for _ in range(3):
+        model.encode_img(image, (ids, mask))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 40
+    for _ in range(n):
+        model.encode_img(image, (ids, mask))
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / n
+    print(f"HK_GRAPH={os.environ.get('HK_GRAPH','1')} B={B} T={T}: {ms:.3f} ms/call  {B/ms*1e3:.1f} clips/s", flush=True)
