@@ -64,3 +64,30 @@ SMALL = EncoderConfig(
     qf_intermediate=512, qf_vocab=1000, qf_max_pos=64, num_query_token=8,
     extra_num_query_token=8, llama_hidden=256,
 )
+
+
+@dataclass(frozen=True)
+class LlmConfig:
+    """Shape of the LLaMA decoder that consumes encode_img's output (row f1): Vicuna-7B-v0's config.json values,
+    i.e. LlamaConfig defaults (models/blip2/modeling_llama.py:16, hawkeye_it.py:112-133)."""
+    hidden_size: int = 4096
+    num_hidden_layers: int = 32
+    num_attention_heads: int = 32
+    intermediate_size: int = 11008
+    vocab_size: int = 32000
+    rms_norm_eps: float = 1e-6
+    rope_base: float = 10000.0
+    max_position_embeddings: int = 2048
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden_size // self.num_attention_heads
+
+    def to_dict(self):
+        return asdict(self)
+
+
+VICUNA_7B = LlmConfig()
+# reduced shape of the committed fixture (tests/golden/llm_small.npz); head size stays 128
+SMALL_LLM = LlmConfig(hidden_size=256, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512, vocab_size=320,
+                      max_position_embeddings=256)

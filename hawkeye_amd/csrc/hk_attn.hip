@@ -374,6 +374,8 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
 
 }  // namespace
 
+int hk_attn_causal_dispatch(const hk_attn_desc* d, void* stream);  // hk_attn_causal.hip
+
 extern "C" int hk_flash_attn_bf16(const hk_attn_desc* d, void* stream) {
     HK_REQUIRE(d != nullptr, "hk_flash_attn_bf16: null descriptor");
     HK_REQUIRE(d->Q && d->K && d->V && d->O, "hk_flash_attn_bf16: null operand pointer");
@@ -383,6 +385,9 @@ extern "C" int hk_flash_attn_bf16(const hk_attn_desc* d, void* stream) {
                "hk_flash_attn_bf16: operands must be 16-byte aligned");
     HK_REQUIRE((d->ldq | d->ldk | d->ldv | d->bsq | d->bsk | d->bsv) % 8 == 0 && (d->ldo | d->bso) % 4 == 0,
                "hk_flash_attn_bf16: strides must keep 16-byte (Q,K,V) / 8-byte (O) alignment");
+    HK_REQUIRE(d->head_dim == 0 || d->head_dim == 64 || d->head_dim == 128,
+               "hk_flash_attn_bf16: head_dim %d not supported (64 or 128)", d->head_dim);
+    if (d->causal != 0 || d->head_dim == 128) return hk_attn_causal_dispatch(d, stream);
     AttnParams p;
     p.Q = reinterpret_cast<const __bf16*>(d->Q);
     p.K = reinterpret_cast<const __bf16*>(d->K);

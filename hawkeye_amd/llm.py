@@ -1,0 +1,240 @@
+"""LLaMA / Vicuna prefill on MI355X: the consumer of encode_img's [B, 96, 4096] output.
+
+Mirrors what the reference runs between `encode_img` and the first generated token:
+embed_tokens_ on the prompt segments + splice of the video tokens (tasks/test.py:79-97, hawkeye_it.py:287-375),
+then LlamaForCausalLM.forward with inputs_embeds (models/blip2/modeling_llama.py:482-611, 615-742): 32 pre-norm
+decoder layers (RMSNorm, q/k/v projections, rotary embedding, causal attention with fp32 softmax, o_proj,
+SwiGLU MLP), final RMSNorm, lm_head on the last position of every row, and the K/V cache generation continues from.
+
+Numerics: bf16 MFMA operands, fp32 accumulation, fp32 residual stream, fp32 norm statistics and softmax (the
+reference runs the LLM in fp16 with fp32 softmax / variance).  LoRA adapters (hawkeye_it.py:170-177, r=16,
+alpha=32 on q_proj / v_proj) are merged into the dense weights at load: W + (alpha / r) B A.
+
+There is no CPU path: everything below enqueues C-ABI calls of libhawkeye_hip.so (include/hawkeye_hip.h).
+"""
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import lib as L
+from . import ops
+from .config import LlmConfig
+
+LOG2E = 1.4426950408889634
+_PREFIXES = ("llama_model.base_model.model.", "llama_model.", "base_model.model.", "")
+
+
+def merge_lora(sd: Dict[str, torch.Tensor], lora_alpha: float = 32.0, r: Optional[int] = None) -> Dict[str, torch.Tensor]:
+    """Fold PEFT LoRA pairs (`X.lora_A[.default].weight` [r, in], `X.lora_B[.default].weight` [out, r]) into
+    `X.weight` and drop them: W' = W + (lora_alpha / r) * B @ A  (what PEFT's merged inference computes)."""
+    out = dict(sd)
+    for ka in [k for k in sd if ".lora_A." in k and k.endswith(".weight")]:
+        kb = ka.replace(".lora_A.", ".lora_B.")
+        base = ka.split(".lora_A.")[0] + ".weight"
+        if kb not in sd or base not in sd:
+            raise RuntimeError(f"merge_lora: {ka} has no matching lora_B / base weight")
+        A, Bm = sd[ka].float(), sd[kb].float()
+        rank = A.shape[0] if r is None else r
+        out[base] = (sd[base].float() + (lora_alpha / rank) * (Bm @ A)).to(sd[base].dtype)
+        del out[ka], out[kb]
+    return out
+
+
+def strip_prefix(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Accept HawkEye_it-level keys (`llama_model.base_model.model.model.layers...` under PEFT, hawkeye_it.py:176)
+    as well as bare LlamaForCausalLM keys (`model.layers...`, `lm_head.weight`)."""
+    for p in _PREFIXES:
+        if any(k.startswith(p + "model.embed_tokens.") for k in sd):
+            return {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
+    raise RuntimeError("no LlamaForCausalLM weights (model.embed_tokens.weight) found in the state dict")
+
+
+class _Plan:
+    def __init__(self):
+        self.ws: Dict[str, torch.Tensor] = {}
+        self.steps: List[Tuple] = []
+        self.keep: List = []
+
+
+class LlamaPrefill:
+    """prefill(src | inputs_embeds, attention_mask, video) -> dict(hidden, logits, kv)."""
+
+    def __init__(self, cfg: LlmConfig = LlmConfig(), device="cuda"):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("LlamaPrefill runs on an MI355X only (device must be cuda:N)")
+        if cfg.head_dim not in (64, 128):
+            raise RuntimeError(f"head size {cfg.head_dim} not supported by the HIP attention kernels (64 or 128)")
+        if cfg.hidden_size % 256 or cfg.intermediate_size % 64:
+            raise RuntimeError("hidden_size must be a multiple of 256 and intermediate_size of 64")
+        self.lib = L.load()
+        self.w: Dict[str, torch.Tensor] = {}
+        self.plans: Dict[Tuple[int, int, bool, bool], _Plan] = {}
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], lora_alpha: float = 32.0):
+        cfg, dev = self.cfg, self.device
+        sd = merge_lora(strip_prefix(sd), lora_alpha)
+        w: Dict[str, torch.Tensor] = {}
+
+        def bf(t):
+            return ops.cast_bf16(t.detach().to(device=dev, dtype=torch.float32).contiguous())
+
+        def f32(t):
+            return t.detach().to(device=dev, dtype=torch.float32).contiguous()
+
+        with torch.cuda.device(dev):
+            w["embed"] = bf(sd["model.embed_tokens.weight"])
+            for i in range(cfg.num_hidden_layers):
+                p, o = f"model.layers.{i}.", f"l{i}."
+                w[o + "qkv"] = bf(torch.cat([sd[p + f"self_attn.{n}_proj.weight"].detach().float() for n in "qkv"]))
+                w[o + "o"] = bf(sd[p + "self_attn.o_proj.weight"])
+                w[o + "gu"] = bf(torch.cat([sd[p + "mlp.gate_proj.weight"].detach().float(),
+                                            sd[p + "mlp.up_proj.weight"].detach().float()]))
+                w[o + "down"] = bf(sd[p + "mlp.down_proj.weight"])
+                w[o + "n1"], w[o + "n2"] = f32(sd[p + "input_layernorm.weight"]), f32(sd[p + "post_attention_layernorm.weight"])
+            w["norm"] = f32(sd["model.norm.weight"])
+            w["lm_head"] = bf(sd["lm_head.weight"])
+            # rotary tables exactly as LlamaRotaryEmbedding builds them (modeling_llama.py:79-89), first half
+            hd = cfg.head_dim
+            inv_freq = 1.0 / (cfg.rope_base ** (torch.arange(0, hd, 2).float() / hd))
+            freqs = torch.einsum("i,j->ij", torch.arange(cfg.max_position_embeddings, dtype=inv_freq.dtype), inv_freq)
+            w["cos"], w["sin"] = freqs.cos().to(dev).contiguous(), freqs.sin().to(dev).contiguous()
+        self.w = w
+        return self
+
+    # ------------------------------------------------------------------ plan
+    def _gemm(self, plan, A, W, Cout, M, N, K, **kw):
+        d = ops.gemm_desc(A, W.data_ptr(), Cout, M, N, K, a_rows=(K, 0, 0), c_rows=(N, 0, 0), **kw)
+        plan.keep.append(d)
+        plan.steps.append((self.lib.hk_gemm_bf16, (C.byref(d),), "hk_gemm_bf16"))
+
+    def _build_plan(self, B: int, S: int, masked: bool) -> _Plan:
+        cfg, dev, w = self.cfg, self.device, self.w
+        D, I, H, hd, Lyr, V = (cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.head_dim,
+                               cfg.num_hidden_layers, cfg.vocab_size)
+        M = B * S
+        plan = _Plan()
+        bf16, f32 = torch.bfloat16, torch.float32
+        with torch.cuda.device(dev):
+            ws = plan.ws
+            ws["src"] = torch.empty((M,), dtype=torch.int64, device=dev)
+            ws["mask"] = torch.empty((B, S), dtype=torch.int64, device=dev)
+            ws["kbias"] = torch.empty((B, S), dtype=f32, device=dev)
+            ws["x"] = torch.empty((M, D), dtype=f32, device=dev)           # residual stream
+            ws["xn"] = torch.empty((M, D), dtype=bf16, device=dev)
+            ws["qkv"] = torch.empty((Lyr, M, 3 * D), dtype=bf16, device=dev)  # per layer: q | k | v; k, v = the KV cache
+            ws["att"] = torch.empty((M, D), dtype=bf16, device=dev)
+            ws["gu"] = torch.empty((M, 2 * I), dtype=bf16, device=dev)
+            ws["act"] = torch.empty((M, I), dtype=bf16, device=dev)
+            ws["last"] = torch.empty((B,), dtype=torch.int64, device=dev)
+            ws["hl_f"] = torch.empty((B, D), dtype=f32, device=dev)
+            ws["hl_b"] = torch.empty((B, D), dtype=bf16, device=dev)
+            ws["logits"] = torch.empty((B, V), dtype=f32, device=dev)
+        P = lambda t: t.data_ptr()  # noqa: E731
+        x, xn, att, gu, act = ws["x"], ws["xn"], ws["att"], ws["gu"], ws["act"]
+        qscale = (hd ** -0.5) * LOG2E
+        eb = 2
+        for i in range(Lyr):
+            o = f"l{i}."
+            qkv = ws["qkv"][i]
+            plan.steps.append((self.lib.hk_rmsnorm, (P(x), L.HK_DT_F32, P(w[o + "n1"]), P(xn), M, D, cfg.rms_norm_eps),
+                               "hk_rmsnorm"))
+            self._gemm(plan, P(xn), w[o + "qkv"], P(qkv), M, 3 * D, D)
+            plan.steps.append((self.lib.hk_rope_bf16, (P(qkv), P(w["cos"]), P(w["sin"]), None, M, H, hd, S,
+                                                       cfg.max_position_embeddings, qscale), "hk_rope_bf16"))
+            ad = ops.attn_desc(P(qkv), P(qkv) + D * eb, P(qkv) + 2 * D * eb, P(att), B, H, S, S,
+                               3 * D, 3 * D, 3 * D, D, S * 3 * D, S * 3 * D, S * 3 * D, S * D,
+                               key_bias=P(ws["kbias"]) if masked else None, head_dim=hd, causal=True)
+            plan.keep.append(ad)
+            plan.steps.append((self.lib.hk_flash_attn_bf16, (C.byref(ad),), "hk_flash_attn_bf16"))
+            self._gemm(plan, P(att), w[o + "o"], P(x), M, D, D, residual=P(x), r_rows=(D, 0, 0), out_f32=True)
+            plan.steps.append((self.lib.hk_rmsnorm, (P(x), L.HK_DT_F32, P(w[o + "n2"]), P(xn), M, D, cfg.rms_norm_eps),
+                               "hk_rmsnorm"))
+            self._gemm(plan, P(xn), w[o + "gu"], P(gu), M, 2 * I, D)
+            plan.steps.append((self.lib.hk_silu_mul_bf16, (P(gu), P(act), M, I), "hk_silu_mul_bf16"))
+            self._gemm(plan, P(act), w[o + "down"], P(x), M, D, I, residual=P(x), r_rows=(D, 0, 0), out_f32=True)
+        plan.steps.append((self.lib.hk_rmsnorm, (P(x), L.HK_DT_F32, P(w["norm"]), P(xn), M, D, cfg.rms_norm_eps), "hk_rmsnorm"))
+        # last valid position of every row -> lm_head (LlamaForCausalLM.forward :688-700; generation reads logits[:, -1])
+        plan.steps.append((self.lib.hk_embed_splice, (P(ws["last"]), P(xn), None, L.HK_DT_BF16, P(ws["hl_f"]), B, D),
+                           "hk_embed_splice"))
+        plan.steps.append((self.lib.hk_cast_f32_bf16, (P(ws["hl_f"]), P(ws["hl_b"]), B * D), "hk_cast_f32_bf16"))
+        self._gemm(plan, P(ws["hl_b"]), w["lm_head"], P(ws["logits"]), B, V, D, out_f32=True)
+        return plan
+
+    # ------------------------------------------------------------------ run
+    @torch.no_grad()
+    def prefill(self, src: Optional[torch.Tensor] = None, video: Optional[torch.Tensor] = None,
+                inputs_embeds: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None):
+        """Either `src` int64 [B,S] (token id >= 0, or -(video row)-1 for a spliced video token) with `video`
+        [B*n, D] bf16/fp32 (encode_img's output), or ready `inputs_embeds` [B,S,D].  attention_mask [B,S] (1 =
+        token, 0 = right/left padding) or None.  Returns {"hidden": bf16 [B,S,D] after the final RMSNorm,
+        "logits": fp32 [B,V] at each row's last valid position, "kv": [(k, v)] per layer as [B,S,H,hd] bf16 views
+        (k post-rotary), valid until the next call with the same (B, S)}.  Padded positions hold unspecified values."""
+        cfg = self.cfg
+        if not self.w:
+            raise RuntimeError("LlamaPrefill: load_state_dict() has not been called")
+        if (src is None) == (inputs_embeds is None):
+            raise RuntimeError("prefill: pass exactly one of src / inputs_embeds")
+        ref = src if src is not None else inputs_embeds
+        B, S = int(ref.shape[0]), int(ref.shape[1])
+        if S > cfg.max_position_embeddings:
+            raise RuntimeError(f"sequence length {S} exceeds max_position_embeddings {cfg.max_position_embeddings}")
+        if ref.device != self.device:
+            raise RuntimeError(f"inputs are on {ref.device}, model on {self.device}")
+        masked = attention_mask is not None
+        key = (B, S, masked)
+        plan = self.plans.get(key)
+        if plan is None:
+            plan = self._build_plan(B, S, masked)
+            self.plans[key] = plan
+        ws = plan.ws
+        D, H, hd = cfg.hidden_size, cfg.num_attention_heads, cfg.head_dim
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            if masked:
+                if attention_mask.shape != (B, S):
+                    raise RuntimeError(f"attention_mask must be [{B},{S}]")
+                ws["mask"].copy_(attention_mask, non_blocking=True)
+                L.check(self.lib.hk_qformer_key_bias(ws["mask"].data_ptr(), ws["kbias"].data_ptr(), B, 0, S, stream),
+                        "hk_qformer_key_bias")
+                # index of the last valid token per row (data movement only: a sum over a [B,S] int mask)
+                last = ws["mask"].sum(1) - 1 + torch.arange(B, device=self.device) * S
+                ws["last"].copy_(last.clamp_min(0))
+            else:
+                ws["last"].copy_(torch.arange(B, device=self.device) * S + (S - 1))
+            if src is not None:
+                ws["src"].copy_(src.reshape(-1), non_blocking=True)
+                vid = None
+                if video is not None:
+                    if video.device != self.device or video.dtype not in (torch.float32, torch.bfloat16):
+                        raise RuntimeError("video must be an fp32/bf16 tensor on the model's GPU")
+                    vid = video.contiguous().reshape(-1, D)
+                if int(ws["src"].min()) < -(0 if vid is None else vid.shape[0]) or int(ws["src"].max()) >= cfg.vocab_size:
+                    raise RuntimeError("prefill: src index outside the vocabulary / video tensor")
+                L.check(self.lib.hk_embed_splice(ws["src"].data_ptr(), self.w["embed"].data_ptr(),
+                                                 None if vid is None else vid.data_ptr(),
+                                                 L.HK_DT_F32 if (vid is not None and vid.dtype == torch.float32) else L.HK_DT_BF16,
+                                                 ws["x"].data_ptr(), B * S, D, stream), "hk_embed_splice")
+            else:
+                if inputs_embeds.shape != (B, S, D):
+                    raise RuntimeError(f"inputs_embeds must be [{B},{S},{D}]")
+                ws["x"].view(B, S, D).copy_(inputs_embeds, non_blocking=True)
+            for fn, args, name in plan.steps:
+                rc = fn(*args, stream)
+                if rc != 0:
+                    L.check(rc, name)
+        kv = [(ws["qkv"][i].view(B, S, 3, H, hd)[:, :, 1], ws["qkv"][i].view(B, S, 3, H, hd)[:, :, 2])
+              for i in range(cfg.num_hidden_layers)]
+        return {"hidden": ws["xn"].view(B, S, D), "logits": ws["logits"], "kv": kv}
+
+
+def prefill_flops(cfg: LlmConfig, B: int, S: int) -> float:
+    """Algorithmic FLOPs of one prefill (2 flops per MAC): projections + SwiGLU MLP for every token, causal attention
+    counted on the lower triangle, lm_head on one position per row; norms / rotary / softmax excluded."""
+    D, I, Lyr = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+    per_tok = 2.0 * (4 * D * D + 3 * D * I)
+    attn = 4.0 * D * S * (S + 1) / 2.0
+    return Lyr * (B * S * per_tok + B * attn) + 2.0 * B * D * cfg.vocab_size

@@ -82,8 +82,10 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     return out
 
 
-def attn_desc(Q, K, V, O, B, H, Nq, Nk, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, key_bias=None) -> L.HkAttnDesc:
+def attn_desc(Q, K, V, O, B, H, Nq, Nk, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, key_bias=None, head_dim=0,
+              causal=False) -> L.HkAttnDesc:
     d = L.HkAttnDesc()
+    d.head_dim, d.causal = head_dim, 1 if causal else 0
     d.Q, d.K, d.V, d.O, d.key_bias = Q, K, V, O, key_bias
     d.B, d.H, d.Nq, d.Nk = B, H, Nq, Nk
     d.ldq, d.ldk, d.ldv, d.ldo = ldq, ldk, ldv, ldo
@@ -96,24 +98,28 @@ def run_attn(d: L.HkAttnDesc):
 
 
 def flash_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, key_bias: Optional[torch.Tensor] = None,
-                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """q [B,Nq,H,64], k/v [B,Nk,H,64] bf16 views (last two dims dense), q pre-scaled by scale*log2(e).
-    key_bias: optional fp32 [B,Nk] additive (natural-log units).  Returns [B,Nq,H,64] bf16."""
+                    out: Optional[torch.Tensor] = None, causal: bool = False) -> torch.Tensor:
+    """q [B,Nq,H,hd], k/v [B,Nk,H,hd] bf16 views (last two dims dense; hd = 64, or 128 for the LLaMA prefill),
+    q pre-scaled by scale*log2(e).  key_bias: optional fp32 [B,Nk] additive (natural-log units).
+    causal: query i sees keys <= i + (Nk - Nq).  Returns [B,Nq,H,hd] bf16."""
+    hd = q.shape[3] if q.dim() == 4 else -1
+    if hd not in (64, 128):
+        raise RuntimeError("flash_attention: head size must be 64 or 128")
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
         _need(t, torch.bfloat16, n)
-        if t.dim() != 4 or t.shape[3] != 64 or t.stride(3) != 1 or t.stride(2) != 64:
-            raise RuntimeError(f"flash_attention: {n} must be [B,N,H,64] with dense (H,64) dims")
+        if t.dim() != 4 or t.shape[3] != hd or t.stride(3) != 1 or t.stride(2) != hd:
+            raise RuntimeError(f"flash_attention: {n} must be [B,N,H,{hd}] with dense (H,{hd}) dims")
     B, Nq, H, _ = q.shape
     Nk = k.shape[1]
     if out is None:
-        out = torch.empty((B, Nq, H, 64), dtype=torch.bfloat16, device=q.device)
+        out = torch.empty((B, Nq, H, hd), dtype=torch.bfloat16, device=q.device)
     if key_bias is not None:
         _need(key_bias, torch.float32, "key_bias")
         if key_bias.shape != (B, Nk) or not key_bias.is_contiguous():
             raise RuntimeError("flash_attention: key_bias must be contiguous [B,Nk]")
     d = attn_desc(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, H, Nq, Nk,
                   q.stride(1), k.stride(1), v.stride(1), out.stride(1),
-                  q.stride(0), k.stride(0), v.stride(0), out.stride(0), _ptr(key_bias))
+                  q.stride(0), k.stride(0), v.stride(0), out.stride(0), _ptr(key_bias), head_dim=hd, causal=causal)
     run_attn(d)
     return out
 
@@ -183,6 +189,75 @@ def pos_embed(T: int, Lp: int, D: int, ckpt_frames: int, device) -> torch.Tensor
     out = torch.empty((T * Lp, D), dtype=torch.float32, device=device)
     with torch.cuda.device(out.device):
         L.check(L.load().hk_pos_embed(out.data_ptr(), T, Lp, D, ckpt_frames, _stream()), "hk_pos_embed")
+    return out
+
+
+def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """LlamaRMSNorm: x [rows, D] fp32 or bf16 -> bf16 [rows, D]; weight fp32 [D]."""
+    if x.dtype not in (torch.float32, torch.bfloat16) or not x.is_cuda or not x.is_contiguous() or x.dim() != 2:
+        raise RuntimeError("rmsnorm: x must be a contiguous 2-D fp32/bf16 GPU tensor")
+    _need(weight, torch.float32, "weight")
+    rows, D = x.shape
+    if out is None:
+        out = torch.empty((rows, D), dtype=torch.bfloat16, device=x.device)
+    L.check(L.load().hk_rmsnorm(x.data_ptr(), L.HK_DT_F32 if x.dtype == torch.float32 else L.HK_DT_BF16,
+                                weight.data_ptr(), out.data_ptr(), rows, D, eps, _stream()), "hk_rmsnorm")
+    return out
+
+
+def rope_(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, H: int, head_dim: int, seq_len: int,
+          q_scale: float = 1.0, position_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Rotary embedding in place on the q|k thirds of qkv bf16 [rows, 3*H*hd]; cos/sin fp32 [P, hd/2]."""
+    _need(qkv, torch.bfloat16, "qkv")
+    _need(cos, torch.float32, "cos")
+    _need(sin, torch.float32, "sin")
+    if qkv.dim() != 2 or qkv.shape[1] != 3 * H * head_dim or not qkv.is_contiguous():
+        raise RuntimeError("rope_: qkv must be contiguous [rows, 3*H*head_dim]")
+    if cos.shape != sin.shape or cos.shape[1] != head_dim // 2 or not cos.is_contiguous() or not sin.is_contiguous():
+        raise RuntimeError("rope_: cos/sin must be contiguous [P, head_dim/2]")
+    if position_ids is not None:
+        _need(position_ids, torch.int32, "position_ids")
+        if position_ids.numel() != qkv.shape[0] or int(position_ids.max()) >= cos.shape[0] or int(position_ids.min()) < 0:
+            raise RuntimeError("rope_: position_ids must hold one in-table position per row")
+    L.check(L.load().hk_rope_bf16(qkv.data_ptr(), cos.data_ptr(), sin.data_ptr(), _ptr(position_ids), qkv.shape[0], H,
+                                  head_dim, seq_len, cos.shape[0], q_scale, _stream()), "hk_rope_bf16")
+    return qkv
+
+
+def silu_mul(gate_up: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """gate_up bf16 [rows, 2*I] (gate | up) -> silu(gate) * up, bf16 [rows, I]."""
+    _need(gate_up, torch.bfloat16, "gate_up")
+    if gate_up.dim() != 2 or gate_up.shape[1] % 2 or not gate_up.is_contiguous():
+        raise RuntimeError("silu_mul: gate_up must be contiguous [rows, 2*I]")
+    rows, I = gate_up.shape[0], gate_up.shape[1] // 2
+    if out is None:
+        out = torch.empty((rows, I), dtype=torch.bfloat16, device=gate_up.device)
+    L.check(L.load().hk_silu_mul_bf16(gate_up.data_ptr(), out.data_ptr(), rows, I, _stream()), "hk_silu_mul_bf16")
+    return out
+
+
+def embed_splice(src: torch.Tensor, table: torch.Tensor, video: Optional[torch.Tensor],
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """src int64 [rows]: >= 0 token id, < 0 video row -src-1; table bf16 [V,D]; video [*,D] bf16/fp32 -> fp32 [rows,D]."""
+    _need(src, torch.int64, "src")
+    _need(table, torch.bfloat16, "table")
+    D = table.shape[1]
+    rows = src.numel()
+    if int(src.max()) >= table.shape[0]:
+        raise RuntimeError("embed_splice: token id outside the embedding table")
+    nvid = 0
+    if video is not None:
+        if video.dtype not in (torch.float32, torch.bfloat16) or not video.is_cuda or not video.is_contiguous():
+            raise RuntimeError("embed_splice: video must be a contiguous fp32/bf16 GPU tensor")
+        video = video.reshape(-1, D)
+        nvid = video.shape[0]
+    if int(src.min()) < -nvid:
+        raise RuntimeError("embed_splice: video row index outside the video tensor")
+    if out is None:
+        out = torch.empty((rows, D), dtype=torch.float32, device=table.device)
+    vdt = L.HK_DT_BF16 if (video is None or video.dtype == torch.bfloat16) else L.HK_DT_F32
+    L.check(L.load().hk_embed_splice(src.contiguous().data_ptr(), table.data_ptr(), _ptr(video), vdt, out.data_ptr(), rows, D,
+                                     _stream()), "hk_embed_splice")
     return out
 
 

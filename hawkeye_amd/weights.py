@@ -18,7 +18,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-from .config import EncoderConfig
+from .config import EncoderConfig, LlmConfig
 
 
 def _rng(name: str, seed: int) -> np.random.Generator:
@@ -139,3 +139,44 @@ def make_instruction_ids(batch: int, max_len: int, vocab: int, seed: int = 0, ra
         ids[b, n - 1] = 102 if vocab > 102 else 2
         mask[b, :n] = 1
     return torch.from_numpy(ids), torch.from_numpy(mask)
+
+
+def make_llm_state_dict(cfg: LlmConfig, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+    """fp32 CPU state dict of LlamaForCausalLM (models/blip2/modeling_llama.py:418-433,612-622 key names).
+    Linear / embedding weights N(0, 0.02) (LlamaPreTrainedModel._init_weights, :392-402); the RMSNorm gains, all ones in
+    the reference, are drawn around 1 so a kernel that drops one fails parity."""
+    sd = OrderedDict()
+    D, I = cfg.hidden_size, cfg.intermediate_size
+    sd["model.embed_tokens.weight"] = _normal("model.embed_tokens.weight", seed, (cfg.vocab_size, D), 0.02)
+    for i in range(cfg.num_hidden_layers):
+        p = f"model.layers.{i}."
+        for n in ("q_proj", "k_proj", "v_proj", "o_proj"):
+            sd[p + f"self_attn.{n}.weight"] = _normal(p + f"self_attn.{n}.weight", seed, (D, D), 0.02)
+        sd[p + "mlp.gate_proj.weight"] = _normal(p + "mlp.gate_proj.weight", seed, (I, D), 0.02)
+        sd[p + "mlp.down_proj.weight"] = _normal(p + "mlp.down_proj.weight", seed, (D, I), 0.02)
+        sd[p + "mlp.up_proj.weight"] = _normal(p + "mlp.up_proj.weight", seed, (I, D), 0.02)
+        sd[p + "input_layernorm.weight"] = _normal(p + "input_layernorm.weight", seed, (D,), 0.1, 1.0)
+        sd[p + "post_attention_layernorm.weight"] = _normal(p + "post_attention_layernorm.weight", seed, (D,), 0.1, 1.0)
+    sd["model.norm.weight"] = _normal("model.norm.weight", seed, (D,), 0.1, 1.0)
+    sd["lm_head.weight"] = _normal("lm_head.weight", seed, (cfg.vocab_size, D), 0.02)
+    return sd
+
+
+def make_prompt(cfg: LlmConfig, B: int, S: int, n_video: int, seed: int, ragged: bool = False):
+    """A spliced prompt: int64 [B, S] source indices (>= 0 token id, < 0 video row -(b*n_video + j) - 1 placed after
+    the first quarter of the prompt, like `###Human: <Video>` + video + `</Video> ...`, tasks/test.py:79-97) and a
+    right-padded attention mask [B, S] (hawkeye_it.py:340-368 pads on the right)."""
+    rng = _rng("prompt", seed)
+    ids = torch.from_numpy(rng.integers(3, cfg.vocab_size, size=(B, S), dtype=np.int64))
+    ids[:, 0] = 1                                       # <s>
+    start = max(1, (S - n_video) // 4)
+    for b in range(B):
+        for j in range(n_video):
+            ids[b, start + j] = -(b * n_video + j) - 1
+    mask = torch.ones(B, S, dtype=torch.int64)
+    if ragged:
+        for b in range(1, B):
+            n_pad = int(rng.integers(1, max(2, (S - start - n_video) // 2)))
+            mask[b, S - n_pad:] = 0
+            ids[b, S - n_pad:] = 2                      # pad = eos (hawkeye_it.py:104)
+    return ids, mask

@@ -73,7 +73,7 @@ typedef struct hk_gemm_desc {
 
 int hk_gemm_bf16(const hk_gemm_desc* d, void* stream);
 
-/* Fused softmax(Q K^T + key_bias) V, head size 64, fp32 online softmax, bf16 in/out.
+/* Fused softmax(Q K^T + key_bias [+ causal mask]) V, head size 64 or 128, fp32 online softmax, bf16 in/out.
  *   Q [B,Nq,H,64], K/V [B,Nk,H,64], O [B,Nq,H,64] addressed through element strides
  *   (token stride ld*, batch stride bs*; head h at column h*64).  Q must already carry
  *   softmax_scale * log2(e) (folded into the producing GEMM); key_bias is an optional
@@ -89,6 +89,8 @@ typedef struct hk_attn_desc {
     int32_t B, H, Nq, Nk;
     int64_t ldq, ldk, ldv, ldo;
     int64_t bsq, bsk, bsv, bso;
+    int32_t head_dim; /* 0 or 64 (ViT, Q-Former), 128 (LLaMA, row f1) */
+    int32_t causal;   /* != 0: query q attends keys <= q + (Nk - Nq)  (modeling_llama.py:25-47) */
 } hk_attn_desc;
 
 int hk_flash_attn_bf16(const hk_attn_desc* d, void* stream);
@@ -122,6 +124,30 @@ int hk_patchify_u8(const uint8_t* frames, void* out, int32_t B, int32_t T, int32
  * (models/blip2/vit.py:163-194): float64 angles, sin/cos, cast to fp32; if ckpt_frames > 0 and != T the
  * [ckpt_frames, L, D] table is linearly interpolated along the frame axis (align_corners=False, vit.py:186). */
 int hk_pos_embed(float* out, int32_t T, int32_t L, int32_t D, int32_t ckpt_frames, void* stream);
+
+/* ---- row f1: LLaMA / Vicuna prefill over the spliced [prompt | 96 video tokens | prompt] sequence ---- */
+
+/* LlamaRMSNorm (models/blip2/modeling_llama.py:57-75): out = weight * x * rsqrt(mean(x^2) + eps), fp32 statistics.
+ * x [rows, D] bf16 or fp32 (in_dtype), weight fp32 [D], out bf16 [rows, D]; D a multiple of 256. */
+int hk_rmsnorm(const void* x, int32_t in_dtype, const float* weight, void* out_bf16, int64_t rows, int32_t D,
+               float eps, void* stream);
+
+/* apply_rotary_pos_emb (modeling_llama.py:108-123) in place on the q and k thirds of a fused bf16
+ * [rows, 3*H*head_dim] buffer; cos/sin fp32 [table_rows, head_dim/2] (the first half of the reference's cached
+ * table, :82-89, whose two halves are equal); position_ids int32 [rows] or NULL (= row % seq_len, the default
+ * arange of LlamaModel.forward :526-533).  q is also multiplied by q_scale (softmax scale * log2 e). */
+int hk_rope_bf16(void* qkv, const float* cos_table, const float* sin_table, const int32_t* position_ids,
+                 int64_t rows, int32_t H, int32_t head_dim, int32_t seq_len, int32_t table_rows, float q_scale,
+                 void* stream);
+
+/* LlamaMLP gate (modeling_llama.py:139-140): out[rows, I] = silu(gate_up[:, :I]) * gate_up[:, I:], bf16. */
+int hk_silu_mul_bf16(const void* gate_up, void* out, int64_t rows, int32_t I, void* stream);
+
+/* embed_tokens (modeling_llama.py:444-455, num_frame_tokens = 0) fused with the splice of the video tokens into the
+ * prompt (tasks/test.py:79-97; hawkeye_it.py:287-375): out fp32 [rows, D]; row r = table[src[r]] if src[r] >= 0,
+ * else video[-src[r] - 1].  table bf16 [V, D]; video [*, D] bf16 or fp32 (video_dtype; may be NULL if unused). */
+int hk_embed_splice(const int64_t* src, const void* table_bf16, const void* video, int32_t video_dtype, float* out,
+                    int64_t rows, int32_t D, void* stream);
 
 /* Q-Former embeddings: rows [0,nq) = query_tokens; rows [nq, nq+Lt) = word_emb[ids] + pos_emb[0..Lt);
  * LayerNorm(eps) -> out_f32 and out_bf16 [B, nq+Lt, d].  (Qformer.py:97-121; hawkeye_it.py:237-241) */

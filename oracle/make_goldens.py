@@ -270,6 +270,44 @@ def frame_transform_goldens(outdir):
     print("wrote frame_transform.npz", tuple(video.shape))
 
 
+def llm_goldens(outdir):
+    """Row f1 fixture: the reference's LlamaForCausalLM (models/blip2/modeling_llama.py, imported unmodified) on a
+    spliced prompt at the reduced shape: per-layer hidden states, final norm, last-position logits, layer-0 K/V."""
+    from hawkeye_amd.config import SMALL_LLM
+    spec = importlib.util.spec_from_file_location("ref_modeling_llama",
+                                                  os.path.join(REF, "models", "blip2", "modeling_llama.py"))
+    ml = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ml)
+    cfg, seed, B, S, nv = SMALL_LLM, 2, 2, 150, 24
+    lc = ml.LlamaConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
+                        num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+                        max_position_embeddings=cfg.max_position_embeddings, rms_norm_eps=cfg.rms_norm_eps,
+                        hidden_act="silu")
+    lc.num_frame_tokens = 0                                                # hawkeye_it.py:113
+    model = ml.LlamaForCausalLM(lc).eval()
+    sd = W.make_llm_state_dict(cfg, seed)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all("rotary_emb" in k for k in missing), (missing, unexpected)
+    src, mask = W.make_prompt(cfg, B, S, nv, seed, ragged=True)
+    video = W._normal("video_tokens", seed, (B * nv, cfg.hidden_size), 0.05)
+    with torch.no_grad():
+        # embed_tokens_ + splice (tasks/test.py:79-97): text segments embedded, video rows concatenated between them
+        tok = model.model.embed_tokens_(src.clamp_min(0))
+        emb = torch.where((src >= 0)[..., None], tok, video[(-src - 1).clamp_min(0)])
+        out = model(inputs_embeds=emb, attention_mask=mask, use_cache=True, output_hidden_states=True, return_dict=True)
+    last = mask.sum(1) - 1
+    rec = {"B": B, "S": S, "n_video": nv, "seed": seed, "src": src.numpy(), "mask": mask.numpy(), "video": video.numpy(),
+           "inputs_embeds": emb.numpy(), "logits_last": out.logits[torch.arange(B), last].numpy(),
+           "k0": out.past_key_values[0][0].numpy(), "v0": out.past_key_values[0][1].numpy()}
+    for i in range(cfg.num_hidden_layers):
+        rec[f"layer{i}"] = out.hidden_states[i + 1].numpy() if i + 1 < cfg.num_hidden_layers else None
+    rec = {k: v for k, v in rec.items() if v is not None}
+    # hidden_states[-1] is the final-norm output (:587-591)
+    rec["final_norm"] = out.hidden_states[-1].numpy()
+    np.savez_compressed(os.path.join(outdir, "llm_small.npz"), **rec)
+    print("wrote llm_small.npz", tuple(out.logits.shape))
+
+
 def main():
     torch.manual_seed(0)
     outdir = os.path.join(REPO, "tests", "golden")
@@ -277,9 +315,13 @@ def main():
     if sys.argv[1:] == ["frames"]:
         frame_transform_goldens(outdir)
         return
+    if sys.argv[1:] == ["llm"]:
+        llm_goldens(outdir)
+        return
     ref_vit, ref_qf = _import_reference()
     pos_embed_goldens(ref_vit, outdir)
     frame_transform_goldens(outdir)
+    llm_goldens(outdir)
     # reduced shape: every stage tensor in full
     run_case("small_video", SMALL, B=2, T=2, Lt=6, seed=3, ragged=True, full_tensors=True,
              ref_vit=ref_vit, ref_qf=ref_qf, outdir=outdir)

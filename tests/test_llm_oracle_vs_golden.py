@@ -1,0 +1,53 @@
+"""Pins oracle/llama_prefill_oracle.py (row f1) to the reference's own LlamaForCausalLM outputs
+(tests/golden/llm_small.npz, made by oracle/make_goldens.py).  Both sides are fp32 CPU programs: tolerance
+2e-5 * max|ref| per tensor (op grouping only)."""
+import os
+
+import numpy as np
+import torch
+
+from hawkeye_amd import weights as W
+from hawkeye_amd.config import SMALL_LLM
+from oracle import llama_prefill_oracle as LO
+
+
+def _close(a, ref, what, rel=2e-5):
+    ref = torch.as_tensor(ref)
+    err = (a.double() - ref.double()).abs().max().item()
+    assert err <= rel * ref.abs().max().item(), (what, err, ref.abs().max().item())
+
+
+def test_llm_oracle_matches_reference_modules(golden_dir):
+    g = np.load(os.path.join(golden_dir, "llm_small.npz"))
+    cfg = SMALL_LLM
+    B, S, nv, seed = int(g["B"]), int(g["S"]), int(g["n_video"]), int(g["seed"])
+    sd = W.make_llm_state_dict(cfg, seed)
+    src, mask = W.make_prompt(cfg, B, S, nv, seed, ragged=True)
+    assert np.array_equal(src.numpy(), g["src"]) and np.array_equal(mask.numpy(), g["mask"])
+    video = torch.from_numpy(g["video"])
+    emb = LO.embed_splice(sd, src, video)
+    assert torch.equal(emb, torch.from_numpy(g["inputs_embeds"]))
+    stages = {}
+    with torch.no_grad():
+        hidden, logits, kv = LO.prefill(sd, cfg.to_dict(), emb, mask, stages)
+    valid = torch.from_numpy(g["mask"]).bool()
+    _close(stages["layer0"][valid], torch.from_numpy(g["layer0"])[valid], "layer0")
+    _close(hidden[valid], torch.from_numpy(g["final_norm"])[valid], "final_norm")
+    _close(logits, g["logits_last"], "logits_last")
+    vk = valid[:, None, :, None].expand_as(kv[0][0])
+    _close(kv[0][0][vk], torch.from_numpy(g["k0"])[vk], "k0")
+    _close(kv[0][1][vk], torch.from_numpy(g["v0"])[vk], "v0")
+
+
+def test_padded_rows_do_not_influence_valid_rows():
+    """Right padding: a row's valid positions are identical whatever sits in its padded tail."""
+    cfg, seed = SMALL_LLM, 5
+    sd = W.make_llm_state_dict(cfg, seed)
+    src, mask = W.make_prompt(cfg, 2, 40, 8, seed, ragged=True)
+    video = W._normal("v", seed, (16, cfg.hidden_size), 0.05)
+    emb = LO.embed_splice(sd, src, video)
+    with torch.no_grad():
+        h1, l1, _ = LO.prefill(sd, cfg.to_dict(), emb, mask)
+        n = int(mask[1].sum())
+        h2, l2, _ = LO.prefill(sd, cfg.to_dict(), emb[1:2, :n], mask[1:2, :n])
+    assert torch.allclose(h1[1, :n], h2[0], atol=1e-5) and torch.allclose(l1[1], l2[0], atol=1e-5)
