@@ -105,6 +105,33 @@ class LlamaPrefill:
         self.w = w
         return self
 
+    def init_random(self, seed: int = 0, std: float = 0.02):
+        """Random weights of this architecture generated on the device (bench / smoke aid: a 7B state dict takes
+        minutes to draw on the host).  Same packed layout as load_state_dict produces."""
+        cfg, dev = self.cfg, self.device
+        D, I, V = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size
+        g = torch.Generator(device=dev).manual_seed(seed)
+        w: Dict[str, torch.Tensor] = {}
+
+        def rnd(*shape):
+            return (torch.randn(shape, generator=g, device=dev, dtype=torch.float32) * std).to(torch.bfloat16)
+
+        with torch.cuda.device(dev):
+            w["embed"] = rnd(V, D)
+            for i in range(cfg.num_hidden_layers):
+                o = f"l{i}."
+                w[o + "qkv"], w[o + "o"], w[o + "gu"], w[o + "down"] = rnd(3 * D, D), rnd(D, D), rnd(2 * I, D), rnd(D, I)
+                w[o + "n1"] = torch.ones(D, device=dev)
+                w[o + "n2"] = torch.ones(D, device=dev)
+            w["norm"] = torch.ones(D, device=dev)
+            w["lm_head"] = rnd(V, D)
+            hd = cfg.head_dim
+            inv_freq = 1.0 / (cfg.rope_base ** (torch.arange(0, hd, 2).float() / hd))
+            freqs = torch.einsum("i,j->ij", torch.arange(cfg.max_position_embeddings, dtype=inv_freq.dtype), inv_freq)
+            w["cos"], w["sin"] = freqs.cos().to(dev).contiguous(), freqs.sin().to(dev).contiguous()
+        self.w = w
+        return self
+
     # ------------------------------------------------------------------ plan
     def _gemm(self, plan, A, W, Cout, M, N, K, **kw):
         d = ops.gemm_desc(A, W.data_ptr(), Cout, M, N, K, a_rows=(K, 0, 0), c_rows=(N, 0, 0), **kw)
