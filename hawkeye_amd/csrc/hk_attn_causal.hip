@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256, 1) void hk_attn_causal_kernel(const CausalPara
     constexpr int NDT = HD / 32;       // 32-dim blocks of O^T
     constexpr int PASSES = KT * CH / 256;  // 16-byte loads per thread per operand per tile
     constexpr int STAGE = 2 * KT * ROWB;
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][K | V][64 keys][ROWB]
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][K | V][64 keys][ROWB], then [2][64] bias
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -76,7 +76,11 @@ __global__ __launch_bounds__(256, 1) void hk_attn_causal_kernel(const CausalPara
     const __bf16* kbase = p.K + (int64_t)b * p.bsk + head * HD + lc * 8;
     const __bf16* vbase = p.V + (int64_t)b * p.bsv + head * HD + lc * 8;
     bf16x8 kr[PASSES], vr[PASSES];
+    float br = 0.f;   // HAS_BIAS: threads 0-63 stage the tile's 64 key-bias values (x log2 e) through LDS
+    float* bias_lds = reinterpret_cast<float*>(smem + 2 * STAGE);
     auto gload = [&](int tile) {
+        if (HAS_BIAS && tid < KT)
+            br = p.key_bias[(int64_t)b * p.Nk + min(tile * KT + tid, p.Nk - 1)] * HK_LOG2E;
 #pragma unroll
         for (int i = 0; i < PASSES; ++i) {
             const int key = min(tile * KT + i * KPP + lkey, p.Nk - 1);
@@ -93,6 +97,7 @@ __global__ __launch_bounds__(256, 1) void hk_attn_causal_kernel(const CausalPara
             *reinterpret_cast<bf16x8*>(ks + key * ROWB + ((lc ^ (key & (CH - 1))) << 4)) = kr[i];
             *reinterpret_cast<bf16x8*>(vs + key * ROWB + (lc << 4)) = vr[i];
         }
+        if (HAS_BIAS && tid < KT) bias_lds[stage * KT + tid] = br;
     };
 
     int koff[NKS];
@@ -140,14 +145,14 @@ __global__ __launch_bounds__(256, 1) void hk_attn_causal_kernel(const CausalPara
                     st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[kt], 0, 0, 0);
                 }
             }
-            if (HAS_BIAS) {
-                const float* kb = p.key_bias + (int64_t)b * p.Nk;
+            if (HAS_BIAS) {   // register 4g + j of st[kt] <-> key 32 kt + 8 g + 4 h + j: four consecutive floats
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int key = t * KT + 32 * kt + (i & 3) + 8 * (i >> 2) + 4 * h;
-                        if (key < p.Nk) st[kt][i] += kb[key] * HK_LOG2E;
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_lds + cur * KT + 32 * kt + 8 * g + 4 * h);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) st[kt][4 * g + j] += bv[j];
                     }
             }
             if (need_mask) {
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(256, 1) void hk_attn_causal_kernel(const CausalPara
 
 template <int HD, bool BIAS>
 int launch_causal(const CausalParams& p, hipStream_t s) {
-    constexpr int LDS = 2 * 2 * KT * HD * 2;
+    constexpr int LDS = 2 * 2 * KT * HD * 2 + (BIAS ? 2 * KT * 4 : 0);
     static bool attr_set = false;  // idempotent
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hk_attn_causal_kernel<HD, BIAS>),

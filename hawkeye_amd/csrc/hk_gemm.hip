@@ -732,7 +732,7 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
     p.gm = gm < 1 ? 1 : gm;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 
-    // The persistent 256x256 kernel once its tiles fill the chip; otherwise the multi-stage kernel, with the
+    // The persistent 256x256 kernel once its tiles fill at least half the chip; otherwise the multi-stage kernel, with the
     // narrower 128x64 tile when 128x128 tiles would leave most CUs idle.  HK_GEMM_VARIANT=0 forces the
     // multi-stage kernel everywhere (A/B aid).
     const long tiles256 = (long)((d->M + 255) / 256) * ((d->N + 255) / 256);
@@ -743,7 +743,10 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
         if (t128 >= 128) return launch<128, 128, 2, 2, 4>(q, s);
         return launch<128, 64, 2, 2, 4>(q, s);
     };
-    if (variant != 0 && tiles256 >= 256 && d->N % 256 == 0) {
+    // from half a chip's worth of 256x256 tiles up (one tile per CU, the rest idle) the ping-pong kernel still beats
+    // the multi-stage one: measured crossover ~128 tiles (prefill o_proj / down_proj at M = 2816: 42.1 -> 39.3 ms)
+    static const int pp_min = getenv("HK_GEMM_PP_MIN") ? atoi(getenv("HK_GEMM_PP_MIN")) : 128;
+    if (variant != 0 && tiles256 >= pp_min && d->N % 256 == 0) {
         // Tail balance: the persistent kernel gives each of the 256 CUs floor or ceil(tiles / 256) tiles, so a
         // last round that is less than half full (e.g. 1568 tiles = 6.125 rounds) idles most of the chip for a
         // whole tile time.  Then the rows of that partial round go to the multi-stage kernel as a second
