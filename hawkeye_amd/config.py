@@ -3,7 +3,7 @@
 Field names follow the reference's config keys (configs/config.json:15-33,
 models/blip2/vit.py:408-422, models/blip2/blip2.py:47-72).
 """
-from dataclasses import dataclass, asdict
+from dataclasses import dataclass, asdict, replace
 
 
 @dataclass(frozen=True)
@@ -64,6 +64,9 @@ SMALL = EncoderConfig(
     qf_intermediate=512, qf_vocab=1000, qf_max_pos=64, num_query_token=8,
     extra_num_query_token=8, llama_hidden=256,
 )
+# Reduced shape of the training fixture (tests/golden/train_small.npz): four Q-Former layers so that cross-attention
+# (layers 0, 2) and non-zero drop-path rates (layers 1..3) both occur more than once.
+SMALL_TRAIN = replace(SMALL, qf_layers=4)
 
 
 @dataclass(frozen=True)

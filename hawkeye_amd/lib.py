@@ -43,6 +43,28 @@ class HkAttnDesc(C.Structure):
     ]
 
 
+class HkDropout(C.Structure):
+    _fields_ = [("p", C.c_float), ("p_path", C.c_float), ("seed", C.c_uint32), ("site", C.c_uint32),
+                ("path_site", C.c_uint32), ("rows_per_sample", C.c_int32)]
+
+
+class HkAttnTrainDesc(C.Structure):
+    _fields_ = [
+        ("Q", C.c_void_p), ("K", C.c_void_p), ("V", C.c_void_p), ("O", C.c_void_p), ("lse", C.c_void_p),
+        ("key_bias", C.c_void_p), ("dO", C.c_void_p), ("dQ", C.c_void_p), ("dK", C.c_void_p), ("dV", C.c_void_p),
+        ("dsum", C.c_void_p),
+        ("B", C.c_int32), ("H", C.c_int32), ("Nq", C.c_int32), ("Nk", C.c_int32),
+        ("ldq", C.c_int64), ("ldk", C.c_int64), ("ldv", C.c_int64), ("ldo", C.c_int64),
+        ("bsq", C.c_int64), ("bsk", C.c_int64), ("bsv", C.c_int64), ("bso", C.c_int64),
+        ("lddq", C.c_int64), ("lddk", C.c_int64), ("lddv", C.c_int64),
+        ("bsdq", C.c_int64), ("bsdk", C.c_int64), ("bsdv", C.c_int64),
+        ("softmax_scale", C.c_float), ("p_drop", C.c_float), ("seed", C.c_uint32), ("site", C.c_uint32),
+    ]
+
+
+HK_LNBWD_MAX_BLOCKS = 256
+HK_COLSUM_MAX_SPLIT = 64
+
 # every symbol include/hawkeye_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "hk_gemm_bf16": (C.c_int, [C.POINTER(HkGemmDesc), C.c_void_p]),
@@ -65,6 +87,24 @@ SYMBOLS = {
                                       C.c_float, C.c_void_p]),
     "hk_qformer_key_bias": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "hk_cast_f32_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "hk_dropout_keep_u32": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32]),
+    "hk_attn_train_fwd": (C.c_int, [C.POINTER(HkAttnTrainDesc), C.c_void_p]),
+    "hk_attn_train_bwd": (C.c_int, [C.POINTER(HkAttnTrainDesc), C.c_void_p]),
+    "hk_drop_add_ln": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(HkRows), C.POINTER(HkDropout), C.POINTER(HkDropout),
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(HkRows),
+                                 C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
+    "hk_layernorm_bwd": (C.c_int, [C.c_void_p, C.POINTER(HkRows), C.c_void_p, C.c_void_p, C.POINTER(HkDropout),
+                                   C.POINTER(HkDropout), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
+    "hk_colsum": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hk_transpose_bf16": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(HkRows), C.c_int64, C.c_int32, C.c_void_p,
+                                    C.c_int64, C.c_void_p]),
+    "hk_gelu_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "hk_gelu_bwd_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "hk_qformer_embed_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                          C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "hk_qformer_embed_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                       C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "hk_mfma_probe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "hk_version": (C.c_int, []),
     "hk_arch": (C.c_char_p, []),

@@ -164,6 +164,97 @@ int hk_qformer_key_bias(const int64_t* text_mask, float* out, int32_t B, int32_t
 /* fp32 -> bf16 (round-to-nearest-even) copy of n elements; weight packing at load time. */
 int hk_cast_f32_bf16(const float* x, void* out, int64_t n, void* stream);
 
+/* ---- row f2: training of the Q-Former / query tokens / llama_proj (stage 3: frozen ViT, tasks/train_it.py:63-80) ----
+ *
+ * Dropout and drop-path (Qformer.py:120,271,315-316,403-404; timm drop_path) use a counter-based hash instead of a
+ * stateful generator, so the backward regenerates every mask from (seed, site, element index) and none is stored:
+ *   key  = fmix32(seed ^ fmix32(site * 0x9E3779B9 + 0x7F4A7C15))        (fmix32 = MurmurHash3's 32-bit finaliser)
+ *   keep = fmix32(idx ^ key) >= (uint32)(p * 2^32) ; kept values are scaled by 1 / (1 - p)
+ * idx = flat element index of the site's own tensor ([rows, D] hidden states; [B,H,Nq,Nk] attention probabilities;
+ * the sample index for drop-path).  hk_dropout_keep_u32 returns fmix32(idx ^ key) on the host (test aid). */
+typedef struct hk_dropout {
+    float p;                 /* element dropout probability, 0 = off */
+    float p_path;            /* drop-path probability (one draw per sample), 0 = off */
+    uint32_t seed;
+    uint32_t site;           /* site id of the element dropout */
+    uint32_t path_site;      /* site id of the drop-path draw */
+    int32_t rows_per_sample; /* rows of one sample (drop-path granularity) */
+} hk_dropout;
+
+uint32_t hk_dropout_keep_u32(uint32_t seed, uint32_t site, uint32_t idx);
+
+/* Attention with dropout on the probabilities, head size 64, and its backward.
+ *   forward:  O = dropout(softmax(Q K^T + key_bias)) V ; lse[b,h,q] = log2-domain logsumexp of row q (saved for backward)
+ *   backward: dQ (gradient w.r.t. the UNscaled query: the kernel multiplies by softmax_scale), dK, dV in bf16;
+ *             dsum fp32 [B,H,Nq] is workspace.  Deterministic: no atomics (a query-side and a key-side kernel).
+ * Q must carry softmax_scale * log2(e) like hk_flash_attn_bf16.  O and dO share ldo/bso.
+ * Replaces: BertSelfAttention.forward in train mode, Qformer.py:218-281 (incl. nn.Dropout :271), and its autograd. */
+typedef struct hk_attn_train_desc {
+    const void* Q;
+    const void* K;
+    const void* V;
+    void* O;
+    float* lse;
+    const float* key_bias;
+    const void* dO;
+    void* dQ;
+    void* dK;
+    void* dV;
+    float* dsum;
+    int32_t B, H, Nq, Nk;
+    int64_t ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso;
+    int64_t lddq, lddk, lddv, bsdq, bsdk, bsdv;
+    float softmax_scale;
+    float p_drop;
+    uint32_t seed, site;
+} hk_attn_train_desc;
+
+int hk_attn_train_fwd(const hk_attn_train_desc* d, void* stream);
+int hk_attn_train_bwd(const hk_attn_train_desc* d, void* stream);
+
+/* z = drop_path(dropout(t)) + res ; y = LayerNorm(z) * gamma + beta [; y = dropout_post(y)], D <= 1024.
+ *   t fp32 [rows, D] plain or NULL; res fp32 row-mapped (res_rows, NULL = plain) or NULL; z_out fp32 [rows, D] or NULL
+ *   (saved for hk_layernorm_bwd); y_f32 / y_bf16 row-mapped by out_rows.  drop / post_drop may be NULL (eval).
+ * Replaces: BertSelfOutput / BertOutput in train mode (dense output -> dropout -> drop_path -> LayerNorm(h + input),
+ *   Qformer.py:313-318, 401-406) and BertEmbeddings' LayerNorm -> dropout (Qformer.py:119-120; post_drop). */
+int hk_drop_add_ln(const float* t, const float* res, const hk_rows* res_rows, const hk_dropout* drop,
+                   const hk_dropout* post_drop, const float* gamma, const float* beta, float* z_out, float* y_f32,
+                   void* y_bf16, const hk_rows* out_rows, int64_t rows, int32_t D, float eps, void* stream);
+
+/* Backward of hk_drop_add_ln.  dy fp32 row-mapped (dy_rows); z = the saved pre-norm rows.
+ *   dz fp32 [rows, D] = gradient of z (= gradient of the residual input); dt_bf16 [rows, D] = dz through the
+ *   drop-path / dropout mask (= gradient of t, the next GEMM operand); dgamma/dbeta fp32 [D] (dbeta == dgamma + D);
+ *   ws: fp32 workspace of HK_LNBWD_MAX_BLOCKS * 2 * D floats (per-workgroup partial sums; deterministic). */
+#define HK_LNBWD_MAX_BLOCKS 256
+int hk_layernorm_bwd(const float* dy, const hk_rows* dy_rows, const float* z, const float* gamma,
+                     const hk_dropout* drop, const hk_dropout* post_drop, float* dz, void* dt_bf16, float* dgamma,
+                     float* dbeta, float* ws, int64_t rows, int32_t D, float eps, void* stream);
+
+/* out[c] = sum over rows of x[r][c] (bias gradients).  x bf16 or fp32 [R, C] with row stride ld; ws: optional fp32
+ * workspace of HK_COLSUM_MAX_SPLIT * C floats (enables a two-stage reduction for tall inputs). */
+#define HK_COLSUM_MAX_SPLIT 64
+int hk_colsum(const void* x, int32_t dtype, int64_t ld, int64_t R, int32_t C, float* out, float* ws, void* stream);
+
+/* out bf16 [C, ldo]: out[c][r] = x[r][c] for r < R, 0 for R <= r < roundup(R, 64).  x bf16 or fp32, rows mapped by
+ * x_rows (NULL = plain [R, C]).  Makes the contraction-contiguous operands of the backward GEMMs:
+ *   dgrad  dX = dY . W      -> hk_gemm_bf16(A = dY,   W = W^T  [in, out])
+ *   wgrad  dW = dY^T . X    -> hk_gemm_bf16(A = dY^T, W = X^T  [in, rows]) */
+int hk_transpose_bf16(const void* x, int32_t in_dtype, const hk_rows* x_rows, int64_t R, int32_t C, void* out,
+                      int64_t ldo, void* stream);
+
+/* exact-erf GELU on bf16 and its backward du = dg * gelu'(u) (BertIntermediate, Qformer.py:387-390); n % 8 == 0. */
+int hk_gelu_bf16(const void* u, void* g, int64_t n, void* stream);
+int hk_gelu_bwd_bf16(const void* dg, const void* u, void* du, int64_t n, void* stream);
+
+/* Pre-LayerNorm rows of BertEmbeddings (Qformer.py:97-118): z fp32 [B, nq+Lt, d] = cat(query_tokens, word[ids] + pos),
+ * and the backward: dquery [nq, d] and dpos rows [0, Lt) are written (sums over the batch), dword rows are
+ * accumulated with atomic adds (the caller zeroes dword first). */
+int hk_qformer_embed_gather(const float* query_tokens, const float* word_emb, const float* pos_emb,
+                            const int64_t* input_ids, float* z, int32_t B, int32_t nq, int32_t Lt, int32_t d,
+                            int32_t vocab, void* stream);
+int hk_qformer_embed_bwd(const float* dz, const int64_t* input_ids, float* dquery, float* dword, float* dpos,
+                         int32_t B, int32_t nq, int32_t Lt, int32_t d, int32_t vocab, void* stream);
+
 /* Measurement aid, no reference counterpart (SURVEY.md §8d asks for a register-resident MFMA-peak probe):
  * `grid` workgroups of 4 waves each issue `iters` x 8 independent v_mfma_f32_16x16x32_bf16 (kind 0) or
  * `iters` x 4 v_mfma_f32_32x32x16_bf16 (kind 1) on fragments loaded once from seed_bf16_2048 (2048 bf16 values);

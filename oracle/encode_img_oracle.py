@@ -109,9 +109,22 @@ def vit_forward(sd, cfg, image_bcthw, pos_embed, stages=None):
 # Q-Former  (models/blip2/Qformer.py)
 # ----------------------------------------------------------------------------
 
-def qf_embeddings(sd, cfg, input_ids, query_embeds):
+# kinds of dropout site inside one BertLayer, shared with oracle/dropout_masks.py and hawkeye_amd/train.py
+SELF_PROB, SELF_HID, SELF_PATH, CROSS_PROB, CROSS_HID, CROSS_PATH, QFFN_HID, QFFN_PATH, TFFN_HID, TFFN_PATH = range(10)
+EMBED_SITE = 4095
+
+
+def _site(layer, kind):
+    return layer * 16 + kind
+
+
+def qf_embeddings(sd, cfg, input_ids, query_embeds, drop=None):
     """Qformer.py:80-121 -- word + absolute position embeddings for the text
-    tokens only, cat(query, text), LayerNorm; dropout off (eval)."""
+    tokens only, cat(query, text), LayerNorm; dropout (:120) only in train mode.
+
+    `drop` (all functions below): None = eval mode.  Otherwise an object with elem(site, x, p) / path(site, x, p)
+    (element dropout / per-sample drop-path with an injected mask, oracle/dropout_masks.MaskDropper) and the
+    probabilities p_hidden, p_attn, path_rates[layer] (blip2.py:62-64)."""
     q = "qformer.bert.embeddings."
     d = cfg["qf_hidden"]
     if input_ids is not None:
@@ -121,10 +134,13 @@ def qf_embeddings(sd, cfg, input_ids, query_embeds):
         emb = torch.cat((query_embeds, emb), dim=1)
     else:
         emb = query_embeds
-    return F.layer_norm(emb, (d,), sd[q + "LayerNorm.weight"], sd[q + "LayerNorm.bias"], cfg["qf_ln_eps"])
+    out = F.layer_norm(emb, (d,), sd[q + "LayerNorm.weight"], sd[q + "LayerNorm.bias"], cfg["qf_ln_eps"])
+    if drop is not None:
+        out = drop.elem(EMBED_SITE, out, drop.p_hidden)                                   # :120
+    return out
 
 
-def qf_attention(sd, pre, cfg, hidden, kv_source, additive_mask):
+def qf_attention(sd, pre, cfg, hidden, kv_source, additive_mask, drop=None, layer=0, kinds=(SELF_PROB, SELF_HID, SELF_PATH)):
     """Qformer.py:182-288 (BertSelfAttention) + 313-318 (BertSelfOutput).
 
     scores = q k^T / sqrt(hd) + mask (scaled AFTER q k^T, :257-260); softmax;
@@ -144,50 +160,60 @@ def qf_attention(sd, pre, cfg, hidden, kv_source, additive_mask):
     if additive_mask is not None:
         scores = scores + additive_mask
     probs = scores.softmax(dim=-1)
+    if drop is not None:
+        probs = drop.elem(_site(layer, kinds[0]), probs, drop.p_attn)                     # :271
     ctx = torch.matmul(probs, v).permute(0, 2, 1, 3).contiguous()
     ctx = ctx.view(ctx.shape[0], ctx.shape[1], d)
     o = pre + "output."
     out = F.linear(ctx, sd[o + "dense.weight"], sd[o + "dense.bias"])
+    if drop is not None:
+        out = drop.elem(_site(layer, kinds[1]), out, drop.p_hidden)                       # :315
+        out = drop.path(_site(layer, kinds[2]), out, drop.path_rates[layer])              # :316
     return F.layer_norm(out + hidden, (d,), sd[o + "LayerNorm.weight"], sd[o + "LayerNorm.bias"],
                         cfg["qf_ln_eps"])
 
 
-def qf_ffn(sd, pre_i, pre_o, cfg, x):
+def qf_ffn(sd, pre_i, pre_o, cfg, x, drop=None, layer=0, kinds=(QFFN_HID, QFFN_PATH)):
     """Qformer.py:387-390, 401-406, 509-517 -- GELU(erf) FFN with post-LN residual."""
     d = cfg["qf_hidden"]
     h = F.gelu(F.linear(x, sd[pre_i + "dense.weight"], sd[pre_i + "dense.bias"]))
     h = F.linear(h, sd[pre_o + "dense.weight"], sd[pre_o + "dense.bias"])
+    if drop is not None:
+        h = drop.elem(_site(layer, kinds[0]), h, drop.p_hidden)                           # :403
+        h = drop.path(_site(layer, kinds[1]), h, drop.path_rates[layer])                  # :404
     return F.layer_norm(h + x, (d,), sd[pre_o + "LayerNorm.weight"], sd[pre_o + "LayerNorm.bias"],
                         cfg["qf_ln_eps"])
 
 
-def qf_layer(sd, cfg, i, hidden, self_mask, image_embeds, cross_mask, query_length):
+def qf_layer(sd, cfg, i, hidden, self_mask, image_embeds, cross_mask, query_length, drop=None):
     """Qformer.py:435-507 (BertLayer.forward)."""
     l = f"qformer.bert.encoder.layer.{i}."
-    att = qf_attention(sd, l + "attention.", cfg, hidden, hidden, self_mask)
+    att = qf_attention(sd, l + "attention.", cfg, hidden, hidden, self_mask, drop, i)
     q_out = att[:, :query_length, :]
     if i % cfg["cross_attention_freq"] == 0:
-        q_out = qf_attention(sd, l + "crossattention.", cfg, q_out, image_embeds, cross_mask)
-    out = qf_ffn(sd, l + "intermediate_query.", l + "output_query.", cfg, q_out)
+        q_out = qf_attention(sd, l + "crossattention.", cfg, q_out, image_embeds, cross_mask, drop, i,
+                             (CROSS_PROB, CROSS_HID, CROSS_PATH))
+    out = qf_ffn(sd, l + "intermediate_query.", l + "output_query.", cfg, q_out, drop, i)
     if att.shape[1] > query_length:
-        out_t = qf_ffn(sd, l + "intermediate.", l + "output.", cfg, att[:, query_length:, :])
+        out_t = qf_ffn(sd, l + "intermediate.", l + "output.", cfg, att[:, query_length:, :], drop, i,
+                       (TFFN_HID, TFFN_PATH))
         out = torch.cat([out, out_t], dim=1)
     return out
 
 
-def qformer_forward(sd, cfg, input_ids, attention_mask, query_embeds, image_embeds, stages=None):
+def qformer_forward(sd, cfg, input_ids, attention_mask, query_embeds, image_embeds, stages=None, drop=None):
     """Qformer.py:837-998 (BertModel.forward), encoder Qformer.py:550-592.
 
     Self mask: (1 - m) * -10000 broadcast over heads and query rows (:818,:834).
     Cross mask: invert_attention_mask(ones) = all zeros (hawkeye_it.py:235)."""
-    hidden = qf_embeddings(sd, cfg, input_ids, query_embeds)
+    hidden = qf_embeddings(sd, cfg, input_ids, query_embeds, drop)
     if stages is not None:
         stages["qf_embeddings"] = hidden
     self_mask = (1.0 - attention_mask[:, None, None, :].to(hidden.dtype)) * -10000.0
     cross_mask = None  # all-zero additive mask
     ql = query_embeds.shape[1]
     for i in range(cfg["qf_layers"]):
-        hidden = qf_layer(sd, cfg, i, hidden, self_mask, image_embeds, cross_mask, ql)
+        hidden = qf_layer(sd, cfg, i, hidden, self_mask, image_embeds, cross_mask, ql, drop)
         if stages is not None:
             stages[f"qf_layer_{i}"] = hidden
     return hidden
@@ -197,7 +223,7 @@ def qformer_forward(sd, cfg, input_ids, attention_mask, query_embeds, image_embe
 # encode_img  (models/hawkeye_it.py:219-270)
 # ----------------------------------------------------------------------------
 
-def encode_img(sd, cfg, image, input_ids, text_mask, pos_embed, stages=None):
+def encode_img(sd, cfg, image, input_ids, text_mask, pos_embed, stages=None, drop=None):
     """image [B,T,3,H,W] fp32; input_ids/text_mask [B,Lt] int64 (stand-in for the
     BertTokenizer output, hawkeye_it.py:243-249); pos_embed [1,T*L,D] is the
     table the encoder holds at call time (pos_embed, or img_pos_embed when T==1,
@@ -218,6 +244,6 @@ def encode_img(sd, cfg, image, input_ids, text_mask, pos_embed, stages=None):
     qt = qt.expand(B, -1, -1)                                         # :241
     nq = qt.shape[1]
     atts = torch.cat([torch.ones(B, nq, dtype=torch.long), text_mask], dim=1)   # :250-251
-    hidden = qformer_forward(sd, cfg, input_ids, atts, qt, emb, stages)          # :253-260
+    hidden = qformer_forward(sd, cfg, input_ids, atts, qt, emb, stages, drop)    # :253-260
     out = F.linear(hidden[:, :nq, :], sd["llama_proj.weight"], sd["llama_proj.bias"])  # :269
     return out, use_image

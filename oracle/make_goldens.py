@@ -21,6 +21,7 @@ all in memory, none touching the reference checkout:
      fixture's frames are generated at the final resolution.
 
 Usage:  python oracle/make_goldens.py            (writes tests/golden/)
+        python oracle/make_goldens.py train      (only the row f2 training fixture)
 """
 import importlib.machinery
 import importlib.util
@@ -138,6 +139,10 @@ def build_reference(cfg: EncoderConfig, sd, ref_vit, ref_qf):
 
 @torch.no_grad()
 def reference_encode_img(m, image, input_ids, text_mask, stages=None):
+    return reference_encode_img_grad(m, image, input_ids, text_mask, stages)
+
+
+def reference_encode_img_grad(m, image, input_ids, text_mask, stages=None):
     """hawkeye_it.py:226-269 around the reference modules (CPU => no autocast)."""
     hooks = []
     if stages is not None:
@@ -308,6 +313,95 @@ def llm_goldens(outdir):
     print("wrote llm_small.npz", tuple(out.logits.shape))
 
 
+def _inject_masks(m, seed):
+    """Train mode with reproducible randomness: every nn.Dropout / DropPath INSTANCE of the reference Q-Former gets a
+    forward that applies the mask of oracle/dropout_masks.py for its site, so the reference's own module graph
+    decides where dropout acts and only the random draw is replaced.  timm (whose drop_path the reference imports,
+    Qformer.py:24) is absent and unpinned in requirements.txt; its published algorithm -- one Bernoulli(keep_prob)
+    draw per sample, kept samples divided by keep_prob -- is what the path() closure below restates."""
+    from oracle import dropout_masks as DM
+
+    def elem(mod, site):
+        p = mod.p
+        mod.forward = lambda x, site=site, p=p: x * torch.from_numpy(DM.keep_mask(seed, site, tuple(x.shape), p)) * float(DM.scale(p))
+
+    def path(mod, site):
+        if isinstance(mod, nn.Identity):
+            return
+        p = mod.drop_prob
+
+        def fwd(x, site=site, p=p):
+            k = torch.from_numpy(DM.keep_mask(seed, site, (x.shape[0],), p))
+            return x * k.view(-1, *([1] * (x.dim() - 1))) * float(DM.scale(p))
+        mod.forward = fwd
+
+    bert = m.qformer.bert
+    elem(bert.embeddings.dropout, DM.EMBED_SITE)
+    for i, layer in enumerate(bert.encoder.layer):
+        elem(layer.attention.self.dropout, DM.site(i, DM.SELF_PROB))
+        elem(layer.attention.output.dropout, DM.site(i, DM.SELF_HID))
+        path(layer.attention.output.drop_path, DM.site(i, DM.SELF_PATH))
+        if layer.has_cross_attention:
+            elem(layer.crossattention.self.dropout, DM.site(i, DM.CROSS_PROB))
+            elem(layer.crossattention.output.dropout, DM.site(i, DM.CROSS_HID))
+            path(layer.crossattention.output.drop_path, DM.site(i, DM.CROSS_PATH))
+        elem(layer.output_query.dropout, DM.site(i, DM.QFFN_HID))
+        path(layer.output_query.drop_path, DM.site(i, DM.QFFN_PATH))
+        elem(layer.output.dropout, DM.site(i, DM.TFFN_HID))
+        path(layer.output.drop_path, DM.site(i, DM.TFFN_PATH))
+
+
+def train_goldens(ref_vit, ref_qf, outdir):
+    """Row f2 fixture: output and parameter gradients of the reference modules for loss = sum(out * G), ViT frozen
+    (hawkeye_it.py:82-91), once with the Q-Former in eval mode and once in train mode with injected masks."""
+    from hawkeye_amd.config import SMALL_TRAIN
+    cfg, seed, drop_seed, B, T, Lt = SMALL_TRAIN, 6, 21, 3, 2, 6
+    sd = W.make_state_dict(cfg, seed)
+    m = build_reference(cfg, sd, ref_vit, ref_qf)
+    image = W.make_clip(B, T, cfg.img_size, seed)
+    ids, mask = W.make_instruction_ids(B, Lt, cfg.qf_vocab, seed, True)
+    m.vision_encoder.encoder.pos_embed = posembed.video_pos_embed(T, cfg.patches_per_frame, cfg.encoder_embed_dim,
+                                                                  cfg.ckpt_num_frame)
+    for p_ in list(m.vision_encoder.parameters()) + list(m.vision_layernorm.parameters()):
+        p_.requires_grad = False
+    G = W._normal("train_dout", seed, (B, cfg.n_query, cfg.llama_hidden), 1.0)
+    rec = dict(B=np.int64(B), T=np.int64(T), Lt=np.int64(Lt), seed=np.int64(seed), drop_seed=np.int64(drop_seed),
+               input_ids=ids.numpy(), text_mask=mask.numpy(), dout=G.numpy())
+    used_ids = torch.unique(ids)
+    rec["used_ids"] = used_ids.numpy()
+    for mode in ("eval", "train"):
+        m.eval()
+        if mode == "train":
+            m.qformer.train()
+            _inject_masks(m, drop_seed)
+        m.zero_grad(set_to_none=True)
+        out, _ = reference_encode_img_grad(m, image, ids, mask)
+        (out * G).sum().backward()
+        rec[f"{mode}.out"] = out.detach().numpy()
+        unused = []
+        for n, p_ in m.named_parameters():
+            if not p_.requires_grad:
+                continue
+            if p_.grad is None:
+                unused.append(n)
+                continue
+            g = p_.grad.detach()
+            rec[f"{mode}.l2.{n}"] = np.float64(g.double().norm().item())
+            if n.endswith("word_embeddings.weight"):
+                rec[f"{mode}.rows.{n}"] = g[used_ids].numpy()
+            elif g.numel() <= 8192:
+                rec[f"{mode}.grad.{n}"] = g.numpy()
+            else:
+                flat = g.reshape(g.shape[0], -1)
+                rows = np.linspace(0, flat.shape[0] - 1, min(8, flat.shape[0])).astype(np.int64)
+                cols = np.linspace(0, flat.shape[1] - 1, min(32, flat.shape[1])).astype(np.int64)
+                rec[f"{mode}.slice.{n}"] = flat[torch.from_numpy(rows)][:, torch.from_numpy(cols)].numpy()
+        rec[f"{mode}.unused"] = np.array(unused)
+        print(mode, "out", tuple(out.shape), "std", float(out.std()), "unused", unused)
+    np.savez_compressed(os.path.join(outdir, "train_small.npz"), **rec)
+    print("wrote train_small.npz")
+
+
 def main():
     torch.manual_seed(0)
     outdir = os.path.join(REPO, "tests", "golden")
@@ -318,10 +412,15 @@ def main():
     if sys.argv[1:] == ["llm"]:
         llm_goldens(outdir)
         return
+    if sys.argv[1:] == ["train"]:
+        ref_vit, ref_qf = _import_reference()
+        train_goldens(ref_vit, ref_qf, outdir)
+        return
     ref_vit, ref_qf = _import_reference()
     pos_embed_goldens(ref_vit, outdir)
     frame_transform_goldens(outdir)
     llm_goldens(outdir)
+    train_goldens(ref_vit, ref_qf, outdir)
     # reduced shape: every stage tensor in full
     run_case("small_video", SMALL, B=2, T=2, Lt=6, seed=3, ragged=True, full_tensors=True,
              ref_vit=ref_vit, ref_qf=ref_qf, outdir=outdir)
