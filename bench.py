@@ -95,6 +95,7 @@ def main():
     ids, mask = ids.to(dev), mask.to(dev)
     gather = (world > 1 and not args.no_gather) or args.force_gather
 
+    @torch.no_grad()
     def step():
         out, _ = model.encode_img(image, (ids, mask))
         if gather:
@@ -184,7 +185,8 @@ def main():
             img1 = W.make_clip(1, T, cfg.img_size, seed).to(dev)
             i1, m1 = W.make_instruction_ids(1, Lt, cfg.qf_vocab, seed)
             model.out_dtype = torch.float32
-            got, _ = model.encode_img(img1, (i1.to(dev), m1.to(dev)))
+            with torch.no_grad():
+                got, _ = model.encode_img(img1, (i1.to(dev), m1.to(dev)))
             a, b = got.double().flatten().cpu(), ref.double().flatten()
             res["parity"] = {"cosine": round(float(a @ b / (a.norm() * b.norm())), 6),
                              "max_rel_err": round(float((a - b).abs().max() / b.abs().max()), 5)}

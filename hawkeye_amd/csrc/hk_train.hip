@@ -49,7 +49,7 @@ constexpr int TS = 72;   // LDS row stride of a 64 x 64 bf16 tile (144 B: 16-byt
 struct AttnT {
     const __bf16 *Q, *K, *V, *dO;
     __bf16 *O, *dQ, *dK, *dV;
-    float *lse, *dsum;
+    float *lse, *dsum, *O32;
     const float* kbias;
     int B, H, Nq, Nk;
     int64_t ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso;
@@ -175,12 +175,18 @@ __global__ __launch_bounds__(256) void attn_train_fwd_kernel(AttnT p) {
         }
     }
     __bf16* Ob = p.O + (int64_t)b * p.bso + h * 64;
+    // fp32 copy of O ([B, Nq, H*64] dense): the backward's dsum = sum_d dO.O must use the unrounded row, otherwise the
+    // rounding of O shifts every dS of the row by P * delta -- a systematic error where attention is diffuse
+    float* O32b = p.O32 ? p.O32 + ((int64_t)b * p.Nq * p.H + h) * 64 : nullptr;
 #pragma unroll
     for (int db = 0; db < 4; ++db)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int q = q0 + 16 * w + 4 * lg + r;
-            if (q < p.Nq) Ob[(int64_t)q * p.ldo + 16 * db + lr] = (__bf16)o[db][r];
+            if (q < p.Nq) {
+                Ob[(int64_t)q * p.ldo + 16 * db + lr] = (__bf16)o[db][r];
+                if (O32b) O32b[(int64_t)q * p.H * 64 + 16 * db + lr] = o[db][r];
+            }
         }
 }
 
@@ -212,8 +218,18 @@ __global__ __launch_bounds__(256) void attn_train_bwd_q_kernel(AttnT p) {
     ao[0] = frag(sA, 16 * w + lr, 8 * lg);
     ao[1] = frag(sA, 16 * w + lr, 8 * lg + 32);
     float dpart = 0.f;
+    if (p.O32) {
+        const int q = q0 + 16 * w + lr;
+        if (q < p.Nq) {
+            const float* orow = p.O32 + (((int64_t)b * p.Nq + q) * p.H + h) * 64;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) dpart += (float)ado[0][e] * (float)ao[0][e] + (float)ado[1][e] * (float)ao[1][e];
+            for (int e = 0; e < 8; ++e)
+                dpart += (float)ado[0][e] * orow[8 * lg + e] + (float)ado[1][e] * orow[8 * lg + 32 + e];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dpart += (float)ado[0][e] * (float)ao[0][e] + (float)ado[1][e] * (float)ao[1][e];
+    }
     dpart += __shfl_xor(dpart, 16);
     dpart += __shfl_xor(dpart, 32);
     if (lg == 0) {
@@ -744,7 +760,7 @@ int fill_attn(const hk_attn_train_desc* d, AttnT& p, bool bwd, const char* who) 
                "%s: operands must be 16-byte aligned", who);
     p.Q = (const __bf16*)d->Q; p.K = (const __bf16*)d->K; p.V = (const __bf16*)d->V; p.dO = (const __bf16*)d->dO;
     p.O = (__bf16*)d->O; p.dQ = (__bf16*)d->dQ; p.dK = (__bf16*)d->dK; p.dV = (__bf16*)d->dV;
-    p.lse = d->lse; p.dsum = d->dsum; p.kbias = d->key_bias;
+    p.lse = d->lse; p.dsum = d->dsum; p.kbias = d->key_bias; p.O32 = d->o_f32;
     p.B = d->B; p.H = d->H; p.Nq = d->Nq; p.Nk = d->Nk;
     p.ldq = d->ldq; p.ldk = d->ldk; p.ldv = d->ldv; p.ldo = d->ldo;
     p.bsq = d->bsq; p.bsk = d->bsk; p.bsv = d->bsv; p.bso = d->bso;

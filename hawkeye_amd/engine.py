@@ -37,6 +37,7 @@ class _Plan:
         self.steps: List[Tuple] = []       # (fn, args) ; stream appended at run time
         self.keep: List = []               # descriptors / ctypes objects kept alive
         self.patch_desc: Optional[L.HkGemmDesc] = None
+        self.vit_end = 0                   # steps[:vit_end] = the ViT up to vision_layernorm (what training reuses)
         self.graphs: Dict[Tuple, "torch.cuda.CUDAGraph"] = {}   # captured calls, keyed by (input kind, table, norm)
 
     def buf(self, name, shape, dtype, device):
@@ -74,8 +75,12 @@ class HipEncoderEngine:
         self.graph_max_frames = int(os.environ.get("HK_GRAPH_MAX_FRAMES", "64"))
 
     # ------------------------------------------------------------------ weights
-    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
-        """Pack a reference-keyed fp32 state dict into device operands."""
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], parts=("vit", "qformer")):
+        """Pack a reference-keyed fp32 state dict into device operands.
+        parts: which half to (re)pack -- "vit" (patch-embed, blocks, vision_layernorm) and/or "qformer"
+        (Q-Former, query tokens, llama_proj); the training path repacks only what changed.
+        Operands that already exist with the same shape are overwritten in place: cached plans hold their
+        addresses."""
         cfg, dev = self.cfg, self.device
         w: Dict[str, torch.Tensor] = {}
 
@@ -88,9 +93,10 @@ class HipEncoderEngine:
         with torch.cuda.device(dev):
             D = cfg.encoder_embed_dim
             p = "vision_encoder.encoder."
-            w["patch.w"] = bf(sd[p + "patch_embed.proj.weight"].detach().reshape(D, -1))
-            w["patch.b"] = f32(p + "patch_embed.proj.bias")
-            for i in range(cfg.run_depth):
+            if "vit" in parts:
+                w["patch.w"] = bf(sd[p + "patch_embed.proj.weight"].detach().reshape(D, -1))
+                w["patch.b"] = f32(p + "patch_embed.proj.bias")
+            for i in range(cfg.run_depth if "vit" in parts else 0):
                 b = f"{p}blocks.{i}."
                 o = f"vit.{i}."
                 w[o + "ln1.g"], w[o + "ln1.b"] = f32(b + "norm1.weight"), f32(b + "norm1.bias")
@@ -101,8 +107,25 @@ class HipEncoderEngine:
                 w[o + "ln2.g"], w[o + "ln2.b"] = f32(b + "norm2.weight"), f32(b + "norm2.bias")
                 w[o + "fc1.w"], w[o + "fc1.b"] = bf(sd[b + "mlp.fc1.weight"].detach()), f32(b + "mlp.fc1.bias")
                 w[o + "fc2.w"], w[o + "fc2.b"] = bf(sd[b + "mlp.fc2.weight"].detach()), f32(b + "mlp.fc2.bias")
-            w["vln.g"], w["vln.b"] = f32("vision_layernorm.weight"), f32("vision_layernorm.bias")
+            if "vit" in parts:
+                w["vln.g"], w["vln.b"] = f32("vision_layernorm.weight"), f32("vision_layernorm.bias")
+            if "qformer" in parts:
+                self._pack_qformer(sd, w, f32, bf)
+            stale = False
+            for k, t in w.items():
+                old = self.w.get(k)
+                if old is not None and old.shape == t.shape and old.dtype == t.dtype:
+                    old.copy_(t)
+                else:
+                    stale = stale or old is not None
+                    self.w[k] = t
+            if stale:
+                self.plans.clear()      # an operand moved: descriptors of cached plans point at the old one
+        return self
 
+    def _pack_qformer(self, sd, w, f32, bf):
+        cfg, dev = self.cfg, self.device
+        with torch.cuda.device(dev):
             q = "qformer.bert."
             w["emb.word"] = f32(q + "embeddings.word_embeddings.weight")
             w["emb.pos"] = f32(q + "embeddings.position_embeddings.weight")
@@ -135,8 +158,6 @@ class HipEncoderEngine:
             w["ckv.w"] = bf(torch.cat([t.to("cpu") for t in kv_w]))
             w["ckv.b"] = torch.cat(kv_b).contiguous()
             w["proj.w"], w["proj.b"] = bf(sd["llama_proj.weight"].detach()), f32("llama_proj.bias")
-        self.w = w
-        return self
 
     # ------------------------------------------------------------------ plan
     def _gemm(self, plan, A, W, Cout, M, N, K, **kw):
@@ -233,6 +254,7 @@ class HipEncoderEngine:
         # vision_layernorm (hawkeye_it.py:234) then the K/V projections of every cross layer at once
         self._tag = "vision_layernorm"
         self._ln(plan, P(x), xf32, w["vln.g"], w["vln.b"], P(xn), None, M, D, cfg.vision_ln_eps)
+        plan.vit_end = len(plan.steps)
         self._tag = "qformer.cross_kv"
         self._gemm(plan, P(xn), w["ckv.w"], P(kvc), M, KVW, D, bias=P(w["ckv.b"]), a_rows=plain(D), c_rows=plain(KVW))
 
@@ -298,6 +320,46 @@ class HipEncoderEngine:
         device with norm = (mean3, std3), default the CLIP statistics of the eval scripts); input_ids/text_mask [B,Lt] int64 (or None);
         pos_embed fp32 [N,D] on the GPU (the table the caller's encoder holds for this T).
         Returns fp32 [B, n_query, llama_hidden] -- a view of the plan's output buffer."""
+        plan, image, u8, B, T, Lt, H, W = self._prepare(image, input_ids, text_mask, pos_embed)
+        cfg, ws, nq = self.cfg, plan.ws, self.cfg.n_query
+        with torch.cuda.device(self.device):
+            use_graph = profile is None and self.use_graphs and B * T <= self.graph_max_frames
+            if use_graph:
+                # Launch-bound sizes (a B=1 call is ~600 launches of a few microseconds each): the whole call is
+                # one hipGraph replay reading a fixed input buffer.  First call of a (plan, table, input kind):
+                # one eager pass (per-kernel static set-up happens there), then capture.
+                name = "in_u8" if u8 else "in_f32"
+                if name not in ws:
+                    plan.buf(name, tuple(image.shape), image.dtype, self.device)
+                ws[name].copy_(image, non_blocking=True)
+                gkey = (name, pos_embed.data_ptr(), norm)
+                g = plan.graphs.get(gkey)
+                if g is None:
+                    self._enqueue(plan, ws[name], u8, norm, pos_embed, B, T, Lt, H, W, None)
+                    torch.cuda.current_stream().synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self._enqueue(plan, ws[name], u8, norm, pos_embed, B, T, Lt, H, W, None)
+                    if len(plan.graphs) >= 4:      # e.g. a caller that assigns a fresh pos_embed tensor per call
+                        plan.graphs.pop(next(iter(plan.graphs)))
+                    plan.graphs[gkey] = g
+                    plan.keep.append(pos_embed)    # the captured launches read this table's address
+                g.replay()
+            else:
+                self._enqueue(plan, image, u8, norm, pos_embed, B, T, Lt, H, W, profile)
+        return ws["out"].view(B, nq, cfg.llama_hidden)
+
+    @torch.no_grad()
+    def forward_vit(self, image, input_ids, text_mask, pos_embed, plan=None, norm=None):
+        """The frozen half of a training call (row f2): patch gather, ViT blocks, vision_layernorm and the text
+        key bias, i.e. the plan's launches up to `vit_end`; leaves image_embeds (bf16) in plan.ws["xn"]."""
+        plan, image, u8, B, T, Lt, H, W = self._prepare(image, input_ids, text_mask, pos_embed)
+        with torch.cuda.device(self.device):
+            self._enqueue(plan, image, u8, norm, pos_embed, B, T, Lt, H, W, None, upto=plan.vit_end)
+        return plan
+
+    def _prepare(self, image, input_ids, text_mask, pos_embed):
+        """Input validation, plan lookup, copy of the token ids / mask into the plan."""
         cfg = self.cfg
         if not self.w:
             raise RuntimeError("HipEncoderEngine: load_state_dict() has not been called")
@@ -329,39 +391,13 @@ class HipEncoderEngine:
         if plan is None:
             plan = self._build_plan(B, T, Lt)
             self.plans[key] = plan
-        ws = plan.ws
-        nq = cfg.n_query
         with torch.cuda.device(self.device):
             if Lt > 0:
-                ws["ids"].copy_(input_ids, non_blocking=True)
-                ws["mask"].copy_(text_mask, non_blocking=True)
-            use_graph = profile is None and self.use_graphs and B * T <= self.graph_max_frames
-            if use_graph:
-                # Launch-bound sizes (a B=1 call is ~600 launches of a few microseconds each): the whole call is
-                # one hipGraph replay reading a fixed input buffer.  First call of a (plan, table, input kind):
-                # one eager pass (per-kernel static set-up happens there), then capture.
-                name = "in_u8" if u8 else "in_f32"
-                if name not in ws:
-                    plan.buf(name, tuple(image.shape), image.dtype, self.device)
-                ws[name].copy_(image, non_blocking=True)
-                gkey = (name, pos_embed.data_ptr(), norm)
-                g = plan.graphs.get(gkey)
-                if g is None:
-                    self._enqueue(plan, ws[name], u8, norm, pos_embed, B, T, Lt, H, W, None)
-                    torch.cuda.current_stream().synchronize()
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
-                        self._enqueue(plan, ws[name], u8, norm, pos_embed, B, T, Lt, H, W, None)
-                    if len(plan.graphs) >= 4:      # e.g. a caller that assigns a fresh pos_embed tensor per call
-                        plan.graphs.pop(next(iter(plan.graphs)))
-                    plan.graphs[gkey] = g
-                    plan.keep.append(pos_embed)    # the captured launches read this table's address
-                g.replay()
-            else:
-                self._enqueue(plan, image, u8, norm, pos_embed, B, T, Lt, H, W, profile)
-        return ws["out"].view(B, nq, cfg.llama_hidden)
+                plan.ws["ids"].copy_(input_ids, non_blocking=True)
+                plan.ws["mask"].copy_(text_mask, non_blocking=True)
+        return plan, image, u8, B, T, Lt, H, W
 
-    def _enqueue(self, plan, image, u8, norm, pos_embed, B, T, Lt, H, W, profile):
+    def _enqueue(self, plan, image, u8, norm, pos_embed, B, T, Lt, H, W, profile, upto=None):
         """Every launch of one call, in order, on torch's current stream (also the body of the captured graph)."""
         cfg, ws = self.cfg, plan.ws
         stream = torch.cuda.current_stream().cuda_stream
@@ -377,7 +413,7 @@ class HipEncoderEngine:
                                               cfg.patch_size, stream), "hk_patchify_bf16")
         plan.patch_desc.residual = pos_embed.data_ptr()
         if profile is None:
-            for fn, args, name, _ in plan.steps:
+            for fn, args, name, _ in plan.steps[:upto]:
                 rc = fn(*args, stream)
                 if rc != 0:
                     L.check(rc, name)

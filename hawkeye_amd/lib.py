@@ -59,6 +59,7 @@ class HkAttnTrainDesc(C.Structure):
         ("lddq", C.c_int64), ("lddk", C.c_int64), ("lddv", C.c_int64),
         ("bsdq", C.c_int64), ("bsdk", C.c_int64), ("bsdv", C.c_int64),
         ("softmax_scale", C.c_float), ("p_drop", C.c_float), ("seed", C.c_uint32), ("site", C.c_uint32),
+        ("o_f32", C.c_void_p),
     ]
 
 

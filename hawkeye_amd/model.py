@@ -28,6 +28,7 @@ import torch.nn as nn
 from . import ops, posembed
 from .config import EncoderConfig
 from .engine import HipEncoderEngine
+from .train import QFormerTrainEngine, trainable_names
 
 
 class _NoForward(nn.Module):
@@ -178,12 +179,42 @@ def disabled_train(self, mode=True):   # blip2.py:90-93
     return self
 
 
+class _EncodeImgFn(torch.autograd.Function):
+    """encode_img as one autograd node (row f2): forward = the HIP training forward, backward = the HIP backward.
+    The trainable parameters are inputs of the node, so autograd (and DistributedDataParallel's hooks,
+    tasks/shared_utils.py:54-59) see real gradients for real nn.Parameters."""
+
+    @staticmethod
+    def forward(ctx, model, image, ids, mask, table, norm, train, seed, *params):
+        eng = model._train_engine
+        out, plan = eng.forward(image, ids, mask, table, train=train, seed=seed, norm=norm)
+        ctx.model, ctx.plan, ctx.generation = model, plan, plan.generation
+        return out.clone()
+
+    @staticmethod
+    def backward(ctx, dout):
+        eng, plan = ctx.model._train_engine, ctx.plan
+        if plan.generation != ctx.generation:
+            raise RuntimeError("encode_img was called again with the same input shape before backward(): the saved "
+                               "activations of this call are gone (one in-flight training call per shape)")
+        eng.backward(plan, dout)
+        ar = eng.arena
+        grads = tuple(ar.grad_view(n, p).clone() if p.requires_grad else None for n, p in zip(ar.names, ar.params))
+        return (None,) * 8 + grads
+
+
 class HawkEyeEncoder(nn.Module):
     """The hot-path half of HawkEye_it (models/hawkeye_it.py:15-270) on MI355X."""
 
     def __init__(self, cfg: EncoderConfig = EncoderConfig(), tokenizer=None, max_txt_len: int = 512,
-                 out_dtype: torch.dtype = torch.float16, residual_dtype: torch.dtype = torch.bfloat16):
+                 out_dtype: torch.dtype = torch.float16, residual_dtype: torch.dtype = torch.bfloat16,
+                 freeze_vit: bool = True, freeze_qformer: bool = True):
+        """freeze_vit / freeze_qformer: hawkeye_it.py:26-27 (both default True there; stage 3 trains with
+        freeze_qformer=False, scripts/train/config_7b_stage3.py).  The ViT has no backward on this path, so
+        freeze_vit=False is refused."""
         super().__init__()
+        if not freeze_vit:
+            raise NotImplementedError("the HIP path keeps the ViT frozen (every shipped config sets freeze_vit=True)")
         self.cfg = cfg
         # registered first: Blip2Base.device is "device of the first parameter" (blip2.py:32-34)
         self.query_tokens = nn.Parameter(torch.zeros(1, cfg.num_query_token, cfg.qf_hidden))
@@ -203,8 +234,27 @@ class HawkEyeEncoder(nn.Module):
         self.out_dtype = out_dtype        # the reference returns fp16 under its autocast (blip2.py:42)
         self.devices = [torch.device("cuda", 0), torch.device("cuda", 0)]
         self._engine: Optional[HipEncoderEngine] = None
-        self._engine_key = None
+        self._engine_key = {"vit": None, "qformer": None}
+        self._train_engine: Optional[QFormerTrainEngine] = None
+        # Q-Former dropout (blip2.py:56-64; config.json:29-31).  Active iff self.qformer.training, like nn.Dropout.
+        self.qformer_hidden_dropout_prob = 0.1
+        self.qformer_attention_probs_dropout_prob = 0.1
+        self.qformer_drop_path_rate = 0.2
+        self._drop_seed, self._drop_calls = 0, 0
         self._table_cache = {}
+        # hawkeye_it.py:82-99
+        for prm in list(self.vision_encoder.parameters()) + list(self.vision_layernorm.parameters()):
+            prm.requires_grad = False
+        self.vision_encoder = self.vision_encoder.eval()
+        self.vision_encoder.train = disabled_train.__get__(self.vision_encoder)
+        self.vision_layernorm = self.vision_layernorm.eval()
+        self.vision_layernorm.train = disabled_train.__get__(self.vision_layernorm)
+        if freeze_qformer:
+            for prm in self.qformer.parameters():
+                prm.requires_grad = False
+            self.qformer = self.qformer.eval()
+            self.qformer.train = disabled_train.__get__(self.qformer)
+            self.query_tokens.requires_grad = False
         # row f4: True = ignore the pos_embed attributes and generate the sinusoid table for the clip's frame
         # count on the device (cached per T); False (default) = the reference contract, read the attribute
         self.device_pos_embed = False
@@ -232,25 +282,74 @@ class HawkEyeEncoder(nn.Module):
             encoder_depth=ve["encoder_depth"], return_index=ve.get("return_index", -1),
             encoder_num_heads=ve["encoder_num_heads"], num_frames=ve["num_frames"],
             num_query_token=config["num_query_token"], extra_num_query_token=config.get("extra_num_query_token", 32))
-        return cls(cfg, max_txt_len=config.get("max_txt_len", 32), **kw)
+        kw.setdefault("freeze_vit", config.get("freeze_vit", True))
+        kw.setdefault("freeze_qformer", config.get("freeze_qformer", True))
+        m = cls(cfg, max_txt_len=config.get("max_txt_len", 32), **kw)
+        m.qformer_hidden_dropout_prob = config.get("qformer_hidden_dropout_prob", 0.1)          # hawkeye_it.py:32-34
+        m.qformer_attention_probs_dropout_prob = config.get("qformer_attention_probs_dropout_prob", 0.1)
+        m.qformer_drop_path_rate = config.get("qformer_drop_path_rate", 0.1)
+        return m
 
     # ---- engine plumbing -----------------------------------------------------------
-    def _weights_key(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+    def _weights_key(self, part: str):
+        vit = part == "vit"
+        return tuple((p.data_ptr(), p._version) for n, p in self.named_parameters()
+                     if n.startswith(("vision_encoder.", "vision_layernorm.")) == vit)
 
-    def sync_engine(self, force: bool = False) -> HipEncoderEngine:
-        """(Re)pack device weights when a parameter was replaced or modified in place."""
+    def sync_engine(self, force: bool = False, parts=("vit", "qformer")) -> HipEncoderEngine:
+        """(Re)pack device weights when a parameter was replaced or modified in place.  The two halves are tracked
+        separately: a training step changes Q-Former parameters only and never repacks the frozen ViT."""
         dev = self.device
         if dev.type != "cuda":
             raise RuntimeError("HawkEyeEncoder.encode_img needs the model on an MI355X (model.to('cuda')); "
                                "there is no CPU path")
-        key = (str(dev), self._weights_key())
-        if force or self._engine is None or self._engine_key != key:
-            if self._engine is None or self._engine.device != dev:
-                self._engine = HipEncoderEngine(self.cfg, dev, self.residual_dtype)
-            self._engine.load_state_dict(self.state_dict())
-            self._engine_key = key
+        if self._engine is None or self._engine.device != dev:
+            self._engine = HipEncoderEngine(self.cfg, dev, self.residual_dtype)
+            self._engine_key = {"vit": None, "qformer": None}
+            self._train_engine = None
+        if self._engine_key["qformer"] is None and "qformer" not in parts:
+            parts = tuple(parts) + ("qformer",)      # plans are built over both halves: pack each at least once
+        todo = []
+        for part in parts:
+            key = (str(dev), self._weights_key(part))
+            if force or self._engine_key[part] != key:
+                todo.append(part)
+                self._engine_key[part] = key
+        if todo:
+            self._engine.load_state_dict(self.state_dict(), parts=tuple(todo))
         return self._engine
+
+    # ---- row f2: training ------------------------------------------------------------
+    def set_dropout_seed(self, seed: int):
+        """Seed of the counter-based dropout / drop-path masks (include/hawkeye_hip.h, hk_dropout).  Call n after this
+        uses seed + n * 0x9E3779B9.  Under data parallelism give every rank its own seed."""
+        self._drop_seed, self._drop_calls = int(seed) & 0xFFFFFFFF, 0
+
+    def trainable_parameters(self):
+        """{state-dict name: nn.Parameter} of what stage 3 trains on this path (hawkeye_it.py:93-99, 183-185)."""
+        named = dict(self.named_parameters())
+        return {n: named[n] for n in trainable_names(self.cfg)}
+
+    def sync_train_engine(self) -> QFormerTrainEngine:
+        eng = self.sync_engine(parts=("vit",))
+        te = self._train_engine
+        if te is None or te.enc is not eng or not te.arena.attached():
+            te = QFormerTrainEngine(eng, self.trainable_parameters(), self.qformer_hidden_dropout_prob,
+                                    self.qformer_attention_probs_dropout_prob, self.qformer_drop_path_rate)
+            self._train_engine = te
+        return te
+
+    def reset_train_engine(self):
+        self._train_engine = None
+
+    def all_reduce_gradients(self, average: bool = True, bucket_mb: int = 64):
+        """Data-parallel gradient exchange of the trainable parameters, straight on the flat gradient arena
+        (hawkeye_amd/dist.py); the alternative to wrapping the model in DistributedDataParallel."""
+        from . import dist as hdist
+        te = self._train_engine
+        if te is None:
+            raise RuntimeError("all_reduce_gradients: no training call has run yet")
+        hdist.all_reduce_flat(te.arena.grad, average=average, bucket_bytes=bucket_mb << 20)
 
     def _table(self, use_image: bool, n_tokens: int, dev) -> torch.Tensor:
         enc = self.vision_encoder.encoder
@@ -293,12 +392,15 @@ class HawkEyeEncoder(nn.Module):
         return ids.to(dev, torch.int64).contiguous(), mask.to(dev, torch.int64).contiguous()
 
     # ---- the hot path --------------------------------------------------------------
-    @torch.no_grad()
     def encode_img(self, image: torch.Tensor, instruction: Union[str, Sequence[str], Tuple[torch.Tensor, torch.Tensor]]):
-        """hawkeye_it.py:219-270.  image [B,T,3,H,W] float on the model's GPU."""
+        """hawkeye_it.py:219-270.  image [B,T,3,H,W] float on the model's GPU.
+
+        Like the reference module it follows the module's mode and autograd's: dropout / drop-path act iff
+        `self.qformer.training` (nn.Dropout semantics; the eval scripts call model.eval()), and the result carries
+        gradients to the Q-Former / query tokens / llama_proj iff grad mode is on and one of them requires grad
+        (stage 3, train_it.py:63-80).  The ViT is frozen (hawkeye_it.py:82-91) and never receives a gradient."""
         return self._encode(image, instruction, None)
 
-    @torch.no_grad()
     def encode_frames(self, frames: torch.Tensor, instruction, mean=ops.CLIP_MEAN, std=ops.CLIP_STD):
         """Row f3: encode_img on decoded frames.  frames [B,T,H,W,3] uint8 (resized + centre-cropped, as
         decord/PIL produce them, tasks/test_recursive_grounding.py:364-385) on the model's GPU; the /255 and
@@ -309,7 +411,11 @@ class HawkEyeEncoder(nn.Module):
 
     def _encode(self, image, instruction, norm):
         device = image.device
-        eng = self.sync_engine()
+        dropout = self.qformer.training
+        need_grad = torch.is_grad_enabled() and any(
+            p.requires_grad for n, p in self.named_parameters() if not n.startswith(("vision_encoder.", "vision_layernorm.")))
+        train_path = dropout or need_grad
+        eng = self.sync_engine(parts=("vit",) if train_path else ("vit", "qformer"))
         if device != eng.device:
             image = image.to(eng.device)
         B, T = image.shape[0], image.shape[1]
@@ -318,6 +424,18 @@ class HawkEyeEncoder(nn.Module):
         ids = mask = None
         if self.qformer_text_input:
             ids, mask = self._tokenize(instruction, B, eng.device)
-        out = eng.forward(image, ids, mask, table, norm=norm)
-        out = out.to(self.out_dtype) if self.out_dtype != torch.float32 else out.clone()
+        if train_path:
+            te = self.sync_train_engine()
+            seed = (self._drop_seed + self._drop_calls * 0x9E3779B9) & 0xFFFFFFFF
+            self._drop_calls += 1
+            if need_grad:
+                out = _EncodeImgFn.apply(self, image, ids, mask, table, norm, dropout, seed, *te.arena.params)
+            else:
+                with torch.no_grad():
+                    out = te.forward(image, ids, mask, table, train=dropout, seed=seed, norm=norm)[0].clone()
+            out = out.to(self.out_dtype) if self.out_dtype != torch.float32 else out
+            return out.to(device), use_image
+        with torch.no_grad():
+            out = eng.forward(image, ids, mask, table, norm=norm)
+            out = out.to(self.out_dtype) if self.out_dtype != torch.float32 else out.clone()
         return out.to(device), use_image

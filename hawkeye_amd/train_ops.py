@@ -27,7 +27,7 @@ def _ref(s):
 
 def attn_train_desc(q, k, v, o, lse, key_bias, B, H, Nq, Nk, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, *, scale,
                     p_drop=0.0, seed=0, site=0, do=None, dq=None, dk=None, dv=None, dsum=None,
-                    lddq=0, lddk=0, lddv=0, bsdq=0, bsdk=0, bsdv=0) -> L.HkAttnTrainDesc:
+                    lddq=0, lddk=0, lddv=0, bsdq=0, bsdk=0, bsdv=0, o_f32=None) -> L.HkAttnTrainDesc:
     """Raw-pointer descriptor (integer device addresses)."""
     d = L.HkAttnTrainDesc()
     d.Q, d.K, d.V, d.O, d.lse, d.key_bias = q, k, v, o, lse, key_bias
@@ -36,6 +36,7 @@ def attn_train_desc(q, k, v, o, lse, key_bias, B, H, Nq, Nk, ldq, ldk, ldv, ldo,
     d.ldq, d.ldk, d.ldv, d.ldo, d.bsq, d.bsk, d.bsv, d.bso = ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso
     d.lddq, d.lddk, d.lddv, d.bsdq, d.bsdk, d.bsdv = lddq, lddk, lddv, bsdq, bsdk, bsdv
     d.softmax_scale, d.p_drop, d.seed, d.site = scale, p_drop, seed & 0xFFFFFFFF, site
+    d.o_f32 = o_f32
     return d
 
 
@@ -46,8 +47,9 @@ def _check_qkv(q, k, v):
             raise RuntimeError(f"attention(train): {n} must be [B,N,H,64] with dense (H,64) dims")
 
 
-def attn_train_fwd(q, k, v, key_bias=None, *, scale, p_drop=0.0, seed=0, site=0):
-    """q [B,Nq,H,64] (pre-scaled by scale*log2 e), k/v [B,Nk,H,64] bf16 -> (o bf16 [B,Nq,H,64], lse fp32 [B,H,Nq])."""
+def attn_train_fwd(q, k, v, key_bias=None, *, scale, p_drop=0.0, seed=0, site=0, o_f32=None):
+    """q [B,Nq,H,64] (pre-scaled by scale*log2 e), k/v [B,Nk,H,64] bf16 -> (o bf16 [B,Nq,H,64], lse fp32 [B,H,Nq]).
+    o_f32: optional dense fp32 [B,Nq,H,64] that receives the unrounded output."""
     _check_qkv(q, k, v)
     B, Nq, H, _ = q.shape
     Nk = k.shape[1]
@@ -55,12 +57,12 @@ def attn_train_fwd(q, k, v, key_bias=None, *, scale, p_drop=0.0, seed=0, site=0)
     lse = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
     d = attn_train_desc(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), _ptr(key_bias), B, H, Nq, Nk,
                         q.stride(1), k.stride(1), v.stride(1), o.stride(1), q.stride(0), k.stride(0), v.stride(0),
-                        o.stride(0), scale=scale, p_drop=p_drop, seed=seed, site=site)
+                        o.stride(0), scale=scale, p_drop=p_drop, seed=seed, site=site, o_f32=_ptr(o_f32))
     L.check(L.load().hk_attn_train_fwd(C.byref(d), _stream()), "hk_attn_train_fwd")
     return o, lse
 
 
-def attn_train_bwd(q, k, v, o, lse, do, key_bias=None, *, scale, p_drop=0.0, seed=0, site=0):
+def attn_train_bwd(q, k, v, o, lse, do, key_bias=None, *, scale, p_drop=0.0, seed=0, site=0, o_f32=None):
     """Gradients (bf16) of attn_train_fwd w.r.t. the unscaled q, k and v."""
     _check_qkv(q, k, v)
     _need(do, torch.bfloat16, "do")
@@ -77,7 +79,7 @@ def attn_train_bwd(q, k, v, o, lse, do, key_bias=None, *, scale, p_drop=0.0, see
                         o.stride(0), scale=scale, p_drop=p_drop, seed=seed, site=site, do=do.data_ptr(),
                         dq=dq.data_ptr(), dk=dk.data_ptr(), dv=dv.data_ptr(), dsum=dsum.data_ptr(),
                         lddq=dq.stride(1), lddk=dk.stride(1), lddv=dv.stride(1), bsdq=dq.stride(0), bsdk=dk.stride(0),
-                        bsdv=dv.stride(0))
+                        bsdv=dv.stride(0), o_f32=_ptr(o_f32))
     L.check(L.load().hk_attn_train_bwd(C.byref(d), _stream()), "hk_attn_train_bwd")
     return dq, dk, dv
 

@@ -187,7 +187,8 @@ uint32_t hk_dropout_keep_u32(uint32_t seed, uint32_t site, uint32_t idx);
  *   forward:  O = dropout(softmax(Q K^T + key_bias)) V ; lse[b,h,q] = log2-domain logsumexp of row q (saved for backward)
  *   backward: dQ (gradient w.r.t. the UNscaled query: the kernel multiplies by softmax_scale), dK, dV in bf16;
  *             dsum fp32 [B,H,Nq] is workspace.  Deterministic: no atomics (a query-side and a key-side kernel).
- * Q must carry softmax_scale * log2(e) like hk_flash_attn_bf16.  O and dO share ldo/bso.
+ * Q must carry softmax_scale * log2(e) like hk_flash_attn_bf16.  O and dO share ldo/bso.  With o_f32 the row sums
+ * dsum = sum_d dO.O use the unrounded output, which keeps dS exact where attention is diffuse (dP - dsum cancels).
  * Replaces: BertSelfAttention.forward in train mode, Qformer.py:218-281 (incl. nn.Dropout :271), and its autograd. */
 typedef struct hk_attn_train_desc {
     const void* Q;
@@ -207,6 +208,7 @@ typedef struct hk_attn_train_desc {
     float softmax_scale;
     float p_drop;
     uint32_t seed, site;
+    float* o_f32;  /* optional fp32 copy of O, dense [B,Nq,H*64]: written by the forward, read by the backward for dsum */
 } hk_attn_train_desc;
 
 int hk_attn_train_fwd(const hk_attn_train_desc* d, void* stream);

@@ -12,6 +12,14 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _inference_mode():
+    # the eval scripts call encode_img under torch.no_grad() (tasks/test.py:495-499); with grad mode on the
+    # call would be recorded for training and run on the training engine (tests/test_gpu_train.py)
+    with torch.no_grad():
+        yield
+
 from hawkeye_amd import posembed, weights as W  # noqa: E402
 from hawkeye_amd.config import FULL, SMALL  # noqa: E402
 from hawkeye_amd.model import HawkEyeEncoder  # noqa: E402

@@ -10,19 +10,7 @@ import torch
 from hawkeye_amd import posembed, weights as W
 from hawkeye_amd.config import SMALL_TRAIN
 from oracle import dropout_masks as DM
-from oracle import encode_img_oracle as O
-
-
-def oracle_train_pass(cfg, sd, image, ids, mask, table, dout, drop):
-    """Shared with the GPU parity test: returns (out, {name: grad}) of loss = sum(out * dout), ViT frozen."""
-    sd = {k: v.clone() for k, v in sd.items()}
-    train = [k for k in sd if k.startswith(("qformer.", "llama_proj.")) or k in ("query_tokens", "extra_query_tokens")]
-    train = [k for k in train if sd[k].is_floating_point()]
-    for k in train:
-        sd[k].requires_grad_(True)
-    out, _ = O.encode_img(sd, cfg.to_dict(), image, ids, mask, table, drop=drop)
-    (out * dout).sum().backward()
-    return out.detach(), {k: (sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])) for k in train}
+from oracle.train_pass import dropper as _dropper, train_pass as oracle_train_pass
 
 
 def load_case(golden_dir):
@@ -37,10 +25,10 @@ def load_case(golden_dir):
 
 
 def dropper(cfg, seed):
-    return DM.MaskDropper(seed, 0.1, 0.1, DM.path_rates(cfg.qf_layers, 0.2))
+    return _dropper(cfg, seed)
 
 
-def check_against_golden(g, mode, out, grads, tol):
+def check_against_golden(g, mode, out, grads, tol, floor=1e-3):
     ref = torch.from_numpy(g[f"{mode}.out"])
     assert (out - ref).abs().max() <= tol * ref.abs().max()
     used = torch.from_numpy(g["used_ids"])
@@ -66,7 +54,7 @@ def check_against_golden(g, mode, out, grads, tol):
             rows = np.linspace(0, flat.shape[0] - 1, min(8, flat.shape[0])).astype(np.int64)
             cols = np.linspace(0, flat.shape[1] - 1, min(32, flat.shape[1])).astype(np.int64)
             got = flat[torch.from_numpy(rows)][:, torch.from_numpy(cols)]
-        scale = max(gr.abs().max().item(), 1e-3)    # key biases have a mathematically zero gradient (softmax shift)
+        scale = max(gr.abs().max().item(), floor)    # key biases have a mathematically zero gradient (softmax shift)
         assert (got - want).abs().max().item() <= tol * scale, (name, kind)
         n_checked += 1
     assert n_checked > 40

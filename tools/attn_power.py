@@ -3,6 +3,8 @@
 from issue-slot limits (the exp / MFMA instruction stream is identical)."""
 import os, sys
 import torch
+
+torch.set_grad_enabled(False)   # inference tools: encode_img follows autograd mode like the reference module
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hawkeye_amd import ops
 from tools.bench_kernels import timeit

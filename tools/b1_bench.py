@@ -2,6 +2,8 @@
 """B=1 call latency (the recursive-grounding shape) with and without hipGraph replay (HK_GRAPH=0/1)."""
 import os, sys, time
 import torch
+
+torch.set_grad_enabled(False)   # inference tools: encode_img follows autograd mode like the reference module
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hawkeye_amd import weights as W
 from hawkeye_amd.config import FULL

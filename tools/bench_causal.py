@@ -2,6 +2,8 @@
 """Causal head-128 attention at the Cfg4 prefill shape (B=8, H=32, S=352) and longer, with / without key mask."""
 import os, sys, math
 import torch
+
+torch.set_grad_enabled(False)   # inference tools: encode_img follows autograd mode like the reference module
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hawkeye_amd import ops
 from tools.bench_kernels import timeit

@@ -2,6 +2,8 @@
 """In-situ per-launch durations of one encode_img call (engine.profile): usage profile_call.py B T"""
 import os, sys
 import torch
+
+torch.set_grad_enabled(False)   # inference tools: encode_img follows autograd mode like the reference module
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hawkeye_amd import weights as W
 from hawkeye_amd.config import FULL

@@ -10,6 +10,8 @@ import time
 
 import torch
 
+torch.set_grad_enabled(False)   # inference tools: encode_img follows autograd mode like the reference module
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hawkeye_amd import weights as W  # noqa: E402
 from hawkeye_amd.config import FULL  # noqa: E402
