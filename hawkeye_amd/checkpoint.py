@@ -102,5 +102,6 @@ def load_packed(model, path: str) -> HipEncoderEngine:
     eng = HipEncoderEngine(model.cfg, dev, model.residual_dtype)
     eng.w = w
     model._engine = eng
-    model._engine_key = (str(dev), model._weights_key())
+    model._engine_key = {part: (str(dev), model._weights_key(part)) for part in ("vit", "qformer")}
+    model._train_engine = None
     return eng
