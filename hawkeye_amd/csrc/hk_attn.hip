@@ -33,6 +33,7 @@ struct AttnParams {
     int B, H, Nq, Nk;
     int64_t ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso;
     int nqb;
+    int o_vec16;  // O rows 16-byte aligned: the epilogue may store whole 128-byte row segments
 };
 
 constexpr int QB = 128;   // query rows per workgroup
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: LDS-DMA bases stay on the scalar unit
     const int r = lane & 31;   // query row within the wave's block (MFMA column)
     const int h = lane >> 5;   // lane half
 
@@ -138,16 +139,22 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
     // lane-linear per wave-instruction (8 keys x 128 B), so the swizzles go on the SOURCE chunk.
     const int ck = (tid & 7) ^ ((lkey >> 1) & 7);
     const int cv = (tid & 7) ^ (((lkey >> 1) & 1) << 2);
-    const __bf16* kd = p.K + (int64_t)b * p.bsk + head * 64 + ck * 8 + (int64_t)lkey * p.ldk;
-    const __bf16* vd = p.V + (int64_t)b * p.bsv + head * 64 + cv * 8 + (int64_t)lkey * p.ldv;
-    auto gdma = [&](int tile) {
-        char* ks = smem + (tile & 1) * (2 * KT * 128) + wave * 8 * 128;
+    // address = wave-uniform base (advanced per tile on the scalar unit) + a constant 32-bit per-lane byte offset
+    const char* kU = reinterpret_cast<const char*>(p.K + (int64_t)b * p.bsk + head * 64);
+    const char* vU = reinterpret_cast<const char*>(p.V + (int64_t)b * p.bsv + head * 64);
+    const uint32_t klane = (uint32_t)(((int64_t)lkey * p.ldk + ck * 8) * 2);
+    const uint32_t vlane = (uint32_t)(((int64_t)lkey * p.ldv + cv * 8) * 2);
+    const int64_t k32b = 64 * p.ldk, v32b = 64 * p.ldv;  // 32 key rows, in bytes
+    auto gdma = [&](int tile, int stage) {
+        char* ks = smem + stage * (2 * KT * 128) + wave * 8 * 128;
         char* vs = ks + KT * 128;
         if ((tile + 1) * KT <= p.Nk) {
-            glds16(kd, ks);
-            glds16(kd + k32, ks + 32 * 128);
-            glds16(vd, vs);
-            glds16(vd + v32, vs + 32 * 128);
+            const char* kt_ = kU + (int64_t)tile * 2 * k32b;
+            const char* vt_ = vU + (int64_t)tile * 2 * v32b;
+            glds16(kt_ + klane, ks);
+            glds16(kt_ + k32b + klane, ks + 32 * 128);
+            glds16(vt_ + vlane, vs);
+            glds16(vt_ + v32b + vlane, vs + 32 * 128);
         } else {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -156,8 +163,6 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
                 glds16(p.V + (int64_t)b * p.bsv + head * 64 + cv * 8 + (int64_t)key * p.ldv, vs + i * 32 * 128);
             }
         }
-        kd += 2 * k32;
-        vd += 2 * v32;
     };
 
     // ---- per-lane LDS read offsets ----
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
 
     const int NT = (p.Nk + KT - 1) / KT;
     if (LOADER == 1) {
-        gdma(0);
+        gdma(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
         gload(0);
@@ -207,12 +212,14 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
     // Either way the decision is wave-uniform, is taken after the previous tile's P.V is complete and
     // before any P of this tile is used, so O, l and this tile's scores are the only things at the
     // old scale when a rescale happens.
-    auto tile = [&](const int t, auto first_c, auto ragged_c) {
+    // The LDS stage (t & 1) is a compile-time argument too -- the steady-state loop is unrolled by two -- so every
+    // fragment address is base register + immediate offset.
+    auto tile = [&](const int t, auto first_c, auto ragged_c, auto cur_c) {
         constexpr bool FIRST = decltype(first_c)::value;
         constexpr bool RAGGED = decltype(ragged_c)::value;
-        const int cur = t & 1;
+        constexpr int cur = decltype(cur_c)::value;
         if (t + 1 < NT) {
-            if (LOADER == 1) gdma(t + 1); else gload(t + 1);
+            if (LOADER == 1) gdma(t + 1, cur ^ 1); else gload(t + 1);
         }
         const char* ks = smem + cur * (2 * KT * 128);
         const char* vs = ks + KT * 128;
@@ -345,18 +352,56 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
 
     using T_ = std::true_type;
     using F_ = std::false_type;
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
     const bool ragged = (p.Nk % KT) != 0;
+    auto last = [&](const int t, auto first_c) {
+        if (t & 1) {
+            if (ragged) tile(t, first_c, T_{}, S1{}); else tile(t, first_c, F_{}, S1{});
+        } else {
+            if (ragged) tile(t, first_c, T_{}, S0{}); else tile(t, first_c, F_{}, S0{});
+        }
+    };
     if (NT == 1) {
-        if (ragged) tile(0, T_{}, T_{}); else tile(0, T_{}, F_{});
+        last(0, T_{});
     } else {
-        tile(0, T_{}, F_{});
-        for (int t = 1; t < NT - 1; ++t) tile(t, F_{}, F_{});
-        if (ragged) tile(NT - 1, F_{}, T_{}); else tile(NT - 1, F_{}, F_{});
+        tile(0, T_{}, F_{}, S0{});
+        int t = 1;
+        for (; t + 1 < NT - 1; t += 2) {
+            tile(t, F_{}, F_{}, S1{});
+            tile(t + 1, F_{}, F_{}, S0{});
+        }
+        if (t < NT - 1) tile(t, F_{}, F_{}, S1{});
+        last(NT - 1, F_{});
     }
 
     // ---- normalise and store: lane (r, h) holds O[q0 + r][32 dt + 8 g + 4 h .. +4] ----
     const float l_tot = half_swap_sum(l_run);
     const float inv = 1.0f / l_tot;
+    if (p.o_vec16) {
+        // Whole 128-byte row segments: the wave's 32 x 64 bf16 block is transposed through its own 4 KB of the
+        // (now idle -- every tile ends in a workgroup barrier) K/V staging area, 16-B chunk c of row r at chunk
+        // c ^ ((r >> 1) & 7), and leaves as 4 stores of 8 rows x 128 B instead of 8 stores of 32 rows x 16 B.
+        char* stg = smem + wave * 4096;
+        const int sw = (r >> 1) & 7;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 o;
+                o[0] = pack_bf16x2(ot[dt][4 * g] * inv, ot[dt][4 * g + 1] * inv);
+                o[1] = pack_bf16x2(ot[dt][4 * g + 2] * inv, ot[dt][4 * g + 3] * inv);
+                *reinterpret_cast<u32x2*>(stg + r * 128 + (((4 * dt + g) ^ sw) << 4) + 8 * h) = o;
+            }
+        __bf16* ob = p.O + (int64_t)b * p.bso + head * 64 + (lane & 7) * 8;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 8 + (lane >> 3);
+            const u32x4 o = *reinterpret_cast<const u32x4*>(stg + row * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4));
+            if (q0 + row < p.Nq) *reinterpret_cast<u32x4*>(ob + (int64_t)(q0 + row) * p.ldo) = o;
+        }
+        return;
+    }
     const int qrow = q0 + r;
     if (qrow < p.Nq) {
         __bf16* op = p.O + (int64_t)b * p.bso + (int64_t)qrow * p.ldo + head * 64 + 4 * h;
@@ -407,6 +452,9 @@ extern "C" int hk_flash_attn_bf16(const hk_attn_desc* d, void* stream) {
     p.bsv = d->bsv;
     p.bso = d->bso;
     p.nqb = (d->Nq + QB - 1) / QB;
+    // HK_ATTN_EPI=0: A/B aid, per-lane 8-byte stores everywhere
+    static const int epi = getenv("HK_ATTN_EPI") ? atoi(getenv("HK_ATTN_EPI")) : 1;
+    p.o_vec16 = (epi != 0 && d->ldo % 8 == 0 && d->bso % 8 == 0) ? 1 : 0;
     const long nwg = (long)p.nqb * d->H * d->B;
     HK_REQUIRE(nwg < (1L << 31), "hk_flash_attn_bf16: grid too large");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -13,7 +13,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhawkeye_hip.so")
+# HK_LIB_PATH: development aid (tools/ab_lib.py times two builds of the library on the same device); never a fallback
+LIB_PATH = os.environ.get("HK_LIB_PATH") or os.path.join(_HERE, "libhawkeye_hip.so")
 
 HK_ACT_NONE, HK_ACT_GELU_ERF = 0, 1
 HK_DT_BF16, HK_DT_F32 = 0, 1
