@@ -46,12 +46,14 @@ def bench_attn(B=32, N=3136, H=16):
     print(f"xattn B={B} Nq=96 Nk={N} H=12: {us:9.1f} us  {4.0*B*12*96*N*64/us/1e6:8.1f} TFLOP/s", flush=True)
 
 
-def bench_gemm(M=100352):
+def bench_gemm(M=100352, only=None):
     for name, N, K, kw in (("qkv", 3072, 1024, {}), ("proj+res", 1024, 1024, {"res": True}),
                            ("fc1+gelu", 4096, 1024, {"act": "gelu"}), ("fc2+res", 1024, 4096, {"res": True}),
                            ("fc1 noact", 4096, 1024, {}), ("ckv", 9216, 1024, {}), ("patch", 1024, 768, {"res": True}),
                            ("proj+res16", 1024, 1024, {"res": True, "bf16res": True}),
                            ("fc2+res16", 1024, 4096, {"res": True, "bf16res": True})):
+        if only and name not in only:
+            continue
         x = torch.randn(M, K, device=DEV).to(torch.bfloat16)
         w = (torch.randn(N, K, device=DEV) * 0.03).to(torch.bfloat16)
         b = torch.randn(N, device=DEV)
@@ -81,5 +83,9 @@ if __name__ == "__main__":
         bench_attn()
     if "gemm" in what:
         bench_gemm()
+    if "gelu" in what:
+        bench_gemm(only=("fc1+gelu", "fc1 noact"))
+    if "hot" in what:   # the four ViT-block GEMMs as the engine runs them (bf16 residual stream)
+        bench_gemm(only=("qkv", "proj+res16", "fc1+gelu", "fc2+res16"))
     if "ln" in what:
         bench_ln()

@@ -7,13 +7,21 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 path = os.environ.setdefault("HK_GEMM_TRACE", "/tmp/gemm_trace.bin")
 from hawkeye_amd import ops
 DEV = "cuda:0"
-M, N, K = 100352, 3072, 1024
+# usage: gemm_trace.py [N K [res16|gelu]]
+M = 100352
+N, K = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (3072, 1024)
+mode = sys.argv[3] if len(sys.argv) > 3 else ""
 x = torch.randn(M, K, device=DEV).to(torch.bfloat16)
 w = (torch.randn(N, K, device=DEV) * 0.03).to(torch.bfloat16)
-out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+b = torch.randn(N, device=DEV)
+out = torch.randn(M, N, device=DEV).to(torch.bfloat16)
 for _ in range(3):
-    ops.linear(x, w, None, out=out)
+    if mode == "res16":
+        ops.linear(x, w, b, residual=out, out_dtype=torch.bfloat16, out=out)
+    else:
+        ops.linear(x, w, b, act="gelu" if mode == "gelu" else "none", out=out)
 torch.cuda.synchronize()
+print(f"N={N} K={K} {mode}")
 a = np.fromfile(path, dtype=np.uint64).reshape(-1, 64).astype(np.int64)
 print("workgroups", a.shape[0])
 t0 = a[:, 1].min()
