@@ -165,8 +165,8 @@ def main():
             if tag in kflops:
                 e["tflops"] = round(kflops[tag] / us / 1e6, 1)
                 e["frac"] = round(kflops[tag] / us / 1e6 / PEAK_BF16_TFLOPS, 4)
-            elif tag in ("vit.ln", "vision_layernorm"):
-                nbytes = R_ * D_ * (2 + (2 if eng.residual_dtype == torch.bfloat16 else 4))
+            elif tag in ("vit.ln", "vision_layernorm", "vit.ln_stats"):
+                nbytes = R_ * D_ * ((2 if tag != "vit.ln_stats" else 0) + (2 if eng.residual_dtype == torch.bfloat16 else 4))
                 e["tb_s"] = round(nbytes / us / 1e6, 2)
                 e["frac_hbm"] = round(nbytes / us / 1e6 / 8.0, 4)
             kern[tag] = e

@@ -24,7 +24,7 @@ from .engine import HipEncoderEngine
 
 HOT_PATH_PREFIXES = ("vision_encoder.", "vision_layernorm.", "qformer.", "query_tokens", "extra_query_tokens",
                      "llama_proj.")
-PACKED_FORMAT = "hawkeye_amd.packed.v1"
+PACKED_FORMAT = "hawkeye_amd.packed.v2"   # v2: norm1/norm2 may be folded into qkv/fc1 (meta "fold_ln")
 
 
 def hot_path_items(state: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
@@ -79,7 +79,8 @@ def save_packed(model, path: str) -> int:
     from safetensors.torch import save_file
     eng: HipEncoderEngine = model.sync_engine()
     tensors = {k: v.detach().to("cpu").contiguous() for k, v in eng.w.items()}
-    meta = {"format": PACKED_FORMAT, "config": json.dumps(model.cfg.to_dict(), sort_keys=True)}
+    meta = {"format": PACKED_FORMAT, "config": json.dumps(model.cfg.to_dict(), sort_keys=True),
+            "fold_ln": "1" if eng.fold_ln else "0"}
     save_file(tensors, path, metadata=meta)
     return os.path.getsize(path)
 
@@ -100,6 +101,9 @@ def load_packed(model, path: str) -> HipEncoderEngine:
             raise RuntimeError(f"{path}: packed for a different EncoderConfig")
         w = {k: f.get_tensor(k).to(dev) for k in f.keys()}
     eng = HipEncoderEngine(model.cfg, dev, model.residual_dtype)
+    eng.fold_ln = meta.get("fold_ln") == "1"   # the file's qkv / fc1 operands are folded (or not); the plan follows
+    if eng.fold_ln and model.residual_dtype != torch.bfloat16:
+        raise RuntimeError(f"{path}: packed with norm1/norm2 folded into qkv/fc1, which needs the bf16 residual stream")
     eng.w = w
     model._engine = eng
     model._engine_key = {part: (str(dev), model._weights_key(part)) for part in ("vit", "qformer")}

@@ -37,6 +37,8 @@ struct GemmParams {
     const float* bias;
     const void* res;
     void* C;
+    const float* row_stats;  // folded LayerNorm of A: [ceil256(M)][2] (mean, rstd) or null
+    const float* col_c;      // with row_stats: [N] column sums of W
     int M, N, K;
     RowMap a, c, r;
     int64_t ldw;
@@ -111,8 +113,14 @@ __device__ __forceinline__ f32x4 load_res4(const GemmParams& p, int64_t off) {
 
 // One lane's 4 consecutive output columns of one row: bias, column scale, activation, residual, store.
 __device__ __forceinline__ void epi_store(const GemmParams& p, f32x4 v, const f32x4 bias, int n, int64_t coff,
-                                          int64_t roff) {
-    v += bias;
+                                          int64_t roff, float rs, float rm) {
+    if (p.row_stats) {  // LayerNorm folded: rstd * acc + (bias' - rstd * mean * colsum)
+        const f32x4 cc = *reinterpret_cast<const f32x4*>(p.col_c + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], rs, __builtin_fmaf(-rm, cc[e], bias[e]));
+    } else {
+        v += bias;
+    }
     if (p.scale_cols != 0 && n < p.scale_cols) v *= p.scale;
     if (p.act == HK_ACT_GELU_ERF) v = p.out_f32 ? gelu_erf4(v) : gelu_erf4_bf16dst(v);
     if (p.res) v += load_res4(p, roff + n);
@@ -177,7 +185,12 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
 // The epilogue transposes each wave's 128x64 sub-tile through a private 4 KB LDS region above the
 // operand buffers (128 KB + 8 x 4 KB = all 160 KB of the CU) and writes whole row segments.
 // EPI selects the one epilogue this instantiation carries: 0 = bf16 out, no residual; 1 = fp32 staging
-// (fp32 out and/or fp32 residual); 2 = bf16 residual stream updated in place.
+// (fp32 out and/or fp32 residual); 2 = bf16 residual stream updated in place; 3 = 0 with the LayerNorm of A folded
+// in (row_stats / col_c).  The folded form is its own instantiation because its extra live values cost the main loop
+// of EPI 0 ~20 % when they share one body (measured in situ), and its row statistics reach the epilogue without
+// registers or exposed latency: at the start of a tile every wave requests the (mean, rstd) pairs of
+// its 128 rows -- 1 KB, one LDS-DMA instruction -- into its idle staging slab; the counted vmcnt of that K-tile's
+// first phase 4 retires it with the operand loads.
 template <int EPI>
 __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
     constexpr int BK = 64;
@@ -326,17 +339,45 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
                 bias[nh][j] = (p.bias != nullptr && n < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + n)
                                                              : f32x4{0.f, 0.f, 0.f, 0.f};
             }
-        auto pre = [&](f32x4 v, int nh, int j) {
+        constexpr bool FOLD = EPI == 3;
+        float rs[2][4], rm[2][4];
+        f32x4 cc[2][2];
+        if (FOLD) {
+            typedef __attribute__((ext_vector_type(2))) float f32x2s;
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    // (mean, rstd) of row mh*64 + i*16 + (lane & 15) of the wave's 128: staged by the main loop
+                    const f32x2s st = *reinterpret_cast<const f32x2s*>(stg + (mh * 64 + i * 16 + (lane & 15)) * 8);
+                    rs[mh][i] = st[1];
+                    rm[mh][i] = st[1] * st[0];
+                }
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int n = n0 + wn * 64 + nh * 32 + j * 16 + (lane >> 4) * 4;
+                    cc[nh][j] = n < p.N ? *reinterpret_cast<const f32x4*>(p.col_c + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+        }
+        auto pre = [&](f32x4 v, int nh, int j, int mh, int i) {
             const int n = n0 + wn * 64 + nh * 32 + j * 16 + (lane >> 4) * 4;
-            v += bias[nh][j];
+            if (FOLD) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v[e] = __builtin_fmaf(v[e], rs[mh][i], __builtin_fmaf(-rm[mh][i], cc[nh][j][e], bias[nh][j][e]));
+            } else {
+                v += bias[nh][j];
+            }
             if (p.scale_cols != 0 && n < p.scale_cols) v *= p.scale;  // uniform test first: most GEMMs scale nothing
-            if (p.act == HK_ACT_GELU_ERF) v = (EPI == 0 || !p.out_f32) ? gelu_erf4_bf16dst(v) : gelu_erf4(v);
+            if (p.act == HK_ACT_GELU_ERF) v = (EPI == 0 || EPI == 3 || !p.out_f32) ? gelu_erf4_bf16dst(v) : gelu_erf4(v);
             return v;
         };
         const int mw = m0 + wm * 128;  // first row / column of this wave's sub-tile
         const int nw = n0 + wn * 64;
         const int r16 = lane & 15, g4 = lane >> 4;
-        if (EPI == 0) {
+        if (EPI == 0 || EPI == 3) {
             // bf16 out, no residual: 32 rows x 128 B per round; 16-B chunk c of row r lives at chunk c ^ (r & 7)
 #pragma unroll
             for (int mh = 0; mh < 2; ++mh)
@@ -348,7 +389,7 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
                         for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
                             for (int j = 0; j < 2; ++j) {
-                                const f32x4 v = pre(acc[mh][nh][i2 * 2 + ii][j], nh, j);
+                                const f32x4 v = pre(acc[mh][nh][i2 * 2 + ii][j], nh, j, mh, i2 * 2 + ii);
                                 u32x2 o;
                                 o[0] = pack_bf16x2(v[0], v[1]);
                                 o[1] = pack_bf16x2(v[2], v[3]);
@@ -393,7 +434,7 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
                             const int ch = nh * 8 + j * 4 + g4;
-                            *reinterpret_cast<f32x4*>(stg + r16 * 256 + ((ch ^ r16) << 4)) = pre(acc[mh][nh][i][j], nh, j);
+                            *reinterpret_cast<f32x4*>(stg + r16 * 256 + ((ch ^ r16) << 4)) = pre(acc[mh][nh][i][j], nh, j, mh, i);
                         }
                     if (rnd < 7) res_load8(rnd + 1, rnxt);
 #pragma unroll
@@ -434,7 +475,7 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const int ch = nh * 8 + j * 4 + g4;
-                        *reinterpret_cast<f32x4*>(stg + r16 * 256 + ((ch ^ r16) << 4)) = pre(acc[mh][nh][i][j], nh, j);
+                        *reinterpret_cast<f32x4*>(stg + r16 * 256 + ((ch ^ r16) << 4)) = pre(acc[mh][nh][i][j], nh, j, mh, i);
                     }
                 if (p.res && rnd < 7) res_load(rnd + 1, rnxt);
 #pragma unroll
@@ -480,6 +521,14 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
     }
     int buf = 0;
     for (int ti = 0; ti < ntile; ++ti) {
+        if (EPI == 3) {
+            // folded LayerNorm: (mean, rstd) of the wave's 128 rows -> its staging slab (idle until the epilogue),
+            // 2 rows per lane.  Issued outside the K loop, whose body stays that of EPI 0; older than every operand
+            // load of this tile, so the first counted vmcnt retires it.
+            int tm_, tn_;
+            tile_coords(c0 + jb + ti * nbx, p.nbm, p.nbn, p.gm, tm_, tn_);
+            glds16(p.row_stats + 2 * ((int64_t)tm_ * 256 + wm * 128 + 2 * lane), stg);
+        }
         for (int t = 0; t < KT; ++t) {
             // phase 1
             load_a(buf, 0);
@@ -630,10 +679,16 @@ __global__ __launch_bounds__(WM* WN * 64) void hk_gemm_kernel(const GemmParams p
         if (m >= p.M) continue;
         const int64_t coff = p.c.off(m + p.m_off);
         const int64_t roff = p.res ? p.r.off(m + p.m_off) : 0;
+        float rs = 1.f, rm = 0.f;
+        if (p.row_stats) {
+            const float mean = p.row_stats[2 * (int64_t)(m + p.m_off)];
+            rs = p.row_stats[2 * (int64_t)(m + p.m_off) + 1];
+            rm = rs * mean;
+        }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int n = ncol + j * 16;
-            if (n < p.N) epi_store(p, acc[i][j], bias[j], n, coff, roff);
+            if (n < p.N) epi_store(p, acc[i][j], bias[j], n, coff, roff, rs, rm);
         }
     }
 }
@@ -729,6 +784,11 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
     HK_REQUIRE(d->scale_cols % 4 == 0, "hk_gemm_bf16: scale_cols must be a multiple of 4");
     HK_REQUIRE(d->res_dtype == HK_DT_BF16 || d->res_dtype == HK_DT_F32, "hk_gemm_bf16: unknown res_dtype %d",
                d->res_dtype);
+    HK_REQUIRE(d->row_stats == nullptr || (d->col_c != nullptr && d->bias != nullptr && d->residual == nullptr &&
+                                           d->out_dtype == HK_DT_BF16),
+               "hk_gemm_bf16: row_stats (folded LayerNorm) needs col_c and bias, bf16 output and no residual");
+    HK_REQUIRE(((uintptr_t)d->row_stats % 16 == 0) && ((uintptr_t)d->col_c % 16 == 0),
+               "hk_gemm_bf16: row_stats / col_c misaligned");
 
     GemmParams p;
     p.A = reinterpret_cast<const __bf16*>(d->A);
@@ -736,6 +796,8 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
     p.bias = d->bias;
     p.res = d->residual;
     p.C = d->C;
+    p.row_stats = d->row_stats;
+    p.col_c = d->col_c;
     p.M = d->M;
     p.N = d->N;
     p.K = d->K;
@@ -798,7 +860,8 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
             }
         }
         int rc;
-        if (!p.out_f32 && !p.res) rc = launch_pp<0>(p, s);
+        if (p.row_stats) rc = launch_pp<3>(p, s);
+        else if (!p.out_f32 && !p.res) rc = launch_pp<0>(p, s);
         else if (!p.out_f32 && p.res_bf16) rc = launch_pp<2>(p, s);
         else rc = launch_pp<1>(p, s);
         if (rc != HK_OK || tail.M == 0) return rc;

@@ -141,6 +141,46 @@ __global__ __launch_bounds__(256) void hk_ln_bf16_kernel(const __bf16* xin, cons
     }
 }
 
+// (mean, rstd) of each bf16 row: the statistics half of hk_ln_bf16_kernel (same two-pass arithmetic, so a GEMM with
+// the LayerNorm folded in sees the statistics the standalone LayerNorm would have used).
+template <int NCH8>
+__global__ __launch_bounds__(256) void hk_row_stats_kernel(const __bf16* xin, float* stats, int64_t rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[NCH8][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH8; ++c) {
+        const int i = (c * 64 + lane) * 8;
+        if (i < D) {
+            const u32x4 w = *reinterpret_cast<const u32x4*>(xin + row * D + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[c][2 * e] = bf16_lo(w[e]);
+                v[c][2 * e + 1] = bf16_hi(w[e]);
+                s += v[c][2 * e] + v[c][2 * e + 1];
+            }
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH8; ++c)
+        if ((c * 64 + lane) * 8 < D) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = v[c][e] - mean;
+                q += d * d;
+            }
+        }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    if (lane == 0) {
+        stats[2 * row] = mean;
+        stats[2 * row + 1] = rstd;
+    }
+}
+
 template <int NCH>
 __global__ __launch_bounds__(256) void hk_qf_embed_kernel(const float* query, const float* wemb, const float* pemb,
                                                           const int64_t* ids, const float* gamma, const float* beta,
@@ -259,6 +299,22 @@ extern "C" int hk_layernorm(const void* x, int32_t in_dtype, const float* add, c
     else if (nch <= 8) launch_ln<8>(ib, x, add, gamma, beta, ob, out_f32, rows, D, eps, s, o_ld, o_rpb, o_bs);
     else launch_ln<16>(ib, x, add, gamma, beta, ob, out_f32, rows, D, eps, s, o_ld, o_rpb, o_bs);
     HK_CHECK_LAUNCH("hk_layernorm");
+    return HK_OK;
+}
+
+extern "C" int hk_row_stats(const void* x_bf16, float* stats, int64_t rows, int32_t D, float eps, void* stream) {
+    HK_REQUIRE(x_bf16 && stats, "hk_row_stats: null pointer");
+    HK_REQUIRE(rows > 0 && D > 0 && D % 8 == 0 && D <= 2048, "hk_row_stats: bad shape rows=%ld D=%d", (long)rows, D);
+    HK_REQUIRE(((uintptr_t)x_bf16 % 16 == 0) && ((uintptr_t)stats % 8 == 0), "hk_row_stats: misaligned operands");
+    HK_REQUIRE((rows + 3) / 4 < (1L << 31), "hk_row_stats: too many rows");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    const __bf16* xb = reinterpret_cast<const __bf16*>(x_bf16);
+    const int n8 = (D + 511) / 512;
+    if (n8 <= 1) hipLaunchKernelGGL((hk_row_stats_kernel<1>), grid, dim3(256), 0, s, xb, stats, rows, D, eps);
+    else if (n8 <= 2) hipLaunchKernelGGL((hk_row_stats_kernel<2>), grid, dim3(256), 0, s, xb, stats, rows, D, eps);
+    else hipLaunchKernelGGL((hk_row_stats_kernel<4>), grid, dim3(256), 0, s, xb, stats, rows, D, eps);
+    HK_CHECK_LAUNCH("hk_row_stats");
     return HK_OK;
 }
 

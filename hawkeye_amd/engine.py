@@ -72,6 +72,10 @@ class HipEncoderEngine:
         # the host-side enqueue it removes was already hidden behind the GPU.  Kept for callers that want the
         # host thread free.
         self.use_graphs = os.environ.get("HK_GRAPH", "0") == "1"
+        # norm1 / norm2 of the ViT blocks folded into the qkv / fc1 GEMMs (statistics pass + row terms in the GEMM
+        # epilogue instead of a LayerNorm pass that writes its output); needs the bf16 residual stream the statistics
+        # kernel reads.  HK_FOLD_LN=0 keeps the standalone LayerNorm (A/B aid).
+        self.fold_ln = residual_dtype == torch.bfloat16 and os.environ.get("HK_FOLD_LN", "1") != "0"
         self.graph_max_frames = int(os.environ.get("HK_GRAPH_MAX_FRAMES", "64"))
 
     # ------------------------------------------------------------------ weights
@@ -100,12 +104,20 @@ class HipEncoderEngine:
                 b = f"{p}blocks.{i}."
                 o = f"vit.{i}."
                 w[o + "ln1.g"], w[o + "ln1.b"] = f32(b + "norm1.weight"), f32(b + "norm1.bias")
-                w[o + "qkv.w"] = bf(sd[b + "attn.qkv.weight"].detach())
                 qb, vb = f32(b + "attn.q_bias"), f32(b + "attn.v_bias")
                 w[o + "qkv.b"] = torch.cat((qb, torch.zeros_like(vb), vb)).contiguous()   # vit.py:85
                 w[o + "proj.w"], w[o + "proj.b"] = bf(sd[b + "attn.proj.weight"].detach()), f32(b + "attn.proj.bias")
                 w[o + "ln2.g"], w[o + "ln2.b"] = f32(b + "norm2.weight"), f32(b + "norm2.bias")
-                w[o + "fc1.w"], w[o + "fc1.b"] = bf(sd[b + "mlp.fc1.weight"].detach()), f32(b + "mlp.fc1.bias")
+                w[o + "fc1.b"] = f32(b + "mlp.fc1.bias")
+                if self.fold_ln:
+                    # gamma into the weight, beta into the bias, column sums for the mean term (ops.fold_layernorm)
+                    for nm, wk, g, bt in (("qkv", b + "attn.qkv.weight", "ln1.g", "ln1.b"),
+                                          ("fc1", b + "mlp.fc1.weight", "ln2.g", "ln2.b")):
+                        w[o + nm + ".w"], w[o + nm + ".c"], w[o + nm + ".b"] = ops.fold_layernorm(
+                            f32(wk), w[o + nm + ".b"], w[o + g], w[o + bt])
+                else:
+                    w[o + "qkv.w"] = bf(sd[b + "attn.qkv.weight"].detach())
+                    w[o + "fc1.w"] = bf(sd[b + "mlp.fc1.weight"].detach())
                 w[o + "fc2.w"], w[o + "fc2.b"] = bf(sd[b + "mlp.fc2.weight"].detach()), f32(b + "mlp.fc2.bias")
             if "vit" in parts:
                 w["vln.g"], w["vln.b"] = f32("vision_layernorm.weight"), f32("vision_layernorm.bias")
@@ -198,6 +210,7 @@ class HipEncoderEngine:
             pa = plan.buf("patches", (M, Kp), bf16, dev)
             x = plan.buf("x", (M, D), self.residual_dtype, dev)
             xn = plan.buf("xn", (M, D), bf16, dev)
+            rstat = plan.buf("rstat", ((M + 255) // 256 * 256, 2), f32, dev) if self.fold_ln else None   # whole 256-row tiles are read
             qkv = plan.buf("qkv", (M, 3 * D), bf16, dev)
             att = plan.buf("att", (M, D), bf16, dev)
             hid = plan.buf("hid", (M, D * cfg.mlp_ratio), bf16, dev)
@@ -232,22 +245,35 @@ class HipEncoderEngine:
         qscale = (64 ** -0.5) * LOG2E
         for i in range(cfg.run_depth):
             o = f"vit.{i}."
-            self._tag = "vit.ln"
-            self._ln(plan, P(x), xf32, w[o + "ln1.g"], w[o + "ln1.b"], P(xn), None, M, D, cfg.vit_ln_eps)
+            fold = {}
+            if self.fold_ln:
+                # vit.py:125 norm1 folded into attn.qkv: statistics of the residual stream, then the GEMM on x itself
+                self._tag = "vit.ln_stats"
+                plan.steps.append((self.lib.hk_row_stats, (P(x), P(rstat), M, D, cfg.vit_ln_eps), "hk_row_stats", self._tag))
+                fold = dict(row_stats=P(rstat), col_c=P(w[o + "qkv.c"]))
+            else:
+                self._tag = "vit.ln"
+                self._ln(plan, P(x), xf32, w[o + "ln1.g"], w[o + "ln1.b"], P(xn), None, M, D, cfg.vit_ln_eps)
             self._tag = "vit.qkv"
-            self._gemm(plan, P(xn), w[o + "qkv.w"], P(qkv), M, 3 * D, D, bias=P(w[o + "qkv.b"]),
-                       a_rows=plain(D), c_rows=plain(3 * D), scale_cols=D, scale=qscale)
+            self._gemm(plan, P(x) if self.fold_ln else P(xn), w[o + "qkv.w"], P(qkv), M, 3 * D, D, bias=P(w[o + "qkv.b"]),
+                       a_rows=plain(D), c_rows=plain(3 * D), scale_cols=D, scale=qscale, **fold)
             self._tag = "vit.attn"
             self._attn(plan, P(qkv), P(qkv) + 2 * D, P(qkv) + 4 * D, P(att), B, Hv, N, N,
                        3 * D, 3 * D, 3 * D, D, N * 3 * D, N * 3 * D, N * 3 * D, N * D)
             self._tag = "vit.proj"
             self._gemm(plan, P(att), w[o + "proj.w"], P(x), M, D, D, bias=P(w[o + "proj.b"]), residual=P(x),
                        a_rows=plain(D), c_rows=plain(D), r_rows=plain(D), **rkw)
-            self._tag = "vit.ln"
-            self._ln(plan, P(x), xf32, w[o + "ln2.g"], w[o + "ln2.b"], P(xn), None, M, D, cfg.vit_ln_eps)
+            if self.fold_ln:
+                self._tag = "vit.ln_stats"
+                plan.steps.append((self.lib.hk_row_stats, (P(x), P(rstat), M, D, cfg.vit_ln_eps), "hk_row_stats", self._tag))
+                fold = dict(row_stats=P(rstat), col_c=P(w[o + "fc1.c"]))
+            else:
+                self._tag = "vit.ln"
+                self._ln(plan, P(x), xf32, w[o + "ln2.g"], w[o + "ln2.b"], P(xn), None, M, D, cfg.vit_ln_eps)
             self._tag = "vit.fc1_gelu"
-            self._gemm(plan, P(xn), w[o + "fc1.w"], P(hid), M, D * cfg.mlp_ratio, D, bias=P(w[o + "fc1.b"]),
-                       a_rows=plain(D), c_rows=plain(D * cfg.mlp_ratio), act=L.HK_ACT_GELU_ERF)
+            self._gemm(plan, P(x) if self.fold_ln else P(xn), w[o + "fc1.w"], P(hid), M, D * cfg.mlp_ratio, D,
+                       bias=P(w[o + "fc1.b"]), a_rows=plain(D), c_rows=plain(D * cfg.mlp_ratio),
+                       act=L.HK_ACT_GELU_ERF, **fold)
             self._tag = "vit.fc2"
             self._gemm(plan, P(hid), w[o + "fc2.w"], P(x), M, D, D * cfg.mlp_ratio, bias=P(w[o + "fc2.b"]),
                        residual=P(x), a_rows=plain(D * cfg.mlp_ratio), c_rows=plain(D), r_rows=plain(D), **rkw)

@@ -31,8 +31,9 @@ def _need(t: torch.Tensor, dtype, name: str):
 
 def gemm_desc(A, W, C_out, M, N, K, *, bias=None, residual=None, a_rows: Rows, c_rows: Rows,
               r_rows: Rows = (0, 0, 0), ldw=None, act=L.HK_ACT_NONE, out_f32=False, res_bf16=False,
-              scale_cols=0, scale=1.0) -> L.HkGemmDesc:
-    """Raw-pointer descriptor; A/W/C_out/bias/residual are integer device addresses."""
+              scale_cols=0, scale=1.0, row_stats=None, col_c=None) -> L.HkGemmDesc:
+    """Raw-pointer descriptor; A/W/C_out/bias/residual (and row_stats/col_c: LayerNorm of A folded into the GEMM,
+    see include/hawkeye_hip.h) are integer device addresses."""
     d = L.HkGemmDesc()
     d.A, d.W, d.bias, d.residual, d.C = A, W, bias, residual, C_out
     d.M, d.N, d.K = M, N, K
@@ -45,6 +46,7 @@ def gemm_desc(A, W, C_out, M, N, K, *, bias=None, residual=None, a_rows: Rows, c
     d.res_dtype = L.HK_DT_BF16 if res_bf16 else L.HK_DT_F32
     d.scale_cols = scale_cols
     d.scale = scale
+    d.row_stats, d.col_c = row_stats, col_c
     return d
 
 
@@ -54,8 +56,10 @@ def run_gemm(d: L.HkGemmDesc):
 
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
            residual: Optional[torch.Tensor] = None, act: str = "none", out_dtype=torch.bfloat16,
-           scale_cols: int = 0, scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out = act((x @ w.T + bias) * colscale) + residual; x [M,K] bf16, w [N,K] bf16."""
+           scale_cols: int = 0, scale: float = 1.0, out: Optional[torch.Tensor] = None,
+           row_stats: Optional[torch.Tensor] = None, col_c: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = act((x @ w.T + bias) * colscale) + residual; x [M,K] bf16, w [N,K] bf16.
+    row_stats [M,2] fp32 + col_c [N] fp32: LayerNorm of x folded into the GEMM (w, bias prepared by fold_layernorm)."""
     _need(x, torch.bfloat16, "x")
     _need(w, torch.bfloat16, "w")
     M, K = x.shape
@@ -78,8 +82,40 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
                   act=L.HK_ACT_GELU_ERF if act == "gelu" else L.HK_ACT_NONE, out_f32=out_dtype == torch.float32,
                   res_bf16=residual is not None and residual.dtype == torch.bfloat16,
                   scale_cols=scale_cols, scale=scale)
+    if row_stats is not None:
+        _need(row_stats, torch.float32, "row_stats")
+        _need(col_c, torch.float32, "col_c")
+        if tuple(row_stats.shape) != (M, 2) or tuple(col_c.shape) != (N,) or not row_stats.is_contiguous():
+            raise RuntimeError("linear: row_stats must be [M,2] and col_c [N]")
+        d.row_stats, d.col_c = row_stats.data_ptr(), col_c.data_ptr()
     run_gemm(d)
     return out
+
+
+def row_stats(x: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(mean, rstd) of each row of a contiguous bf16 [rows, D] matrix -> fp32 [rows, 2]."""
+    _need(x, torch.bfloat16, "x")
+    if x.dim() != 2 or not x.is_contiguous():
+        raise RuntimeError("row_stats: x must be a contiguous [rows, D] matrix")
+    rows, D = x.shape
+    if out is None:
+        out = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+    L.check(L.load().hk_row_stats(x.data_ptr(), out.data_ptr(), rows, D, eps, _stream()), "hk_row_stats")
+    return out
+
+
+def fold_layernorm(weight: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor):
+    """Operands of a Linear whose input LayerNorm is folded into the GEMM (hk_gemm_desc.row_stats):
+    W' = bf16(gamma[k] * weight[n,k]), col_c[n] = sum_k W'[n,k] (of the rounded values, so the mean term cancels
+    exactly against what the MFMA accumulates), bias'[n] = bias[n] + sum_k beta[k] * weight[n,k].  fp32/fp64 host math
+    on whatever device the tensors are on."""
+    w32 = weight.detach().float()
+    wf = (w32 * gamma.detach().float()[None, :]).to(torch.bfloat16).contiguous()
+    col_c = wf.double().sum(dim=1).float().contiguous()
+    b = (w32.double() @ beta.detach().double()).float()
+    if bias is not None:
+        b = b + bias.detach().float()
+    return wf, col_c, b.contiguous()
 
 
 def attn_desc(Q, K, V, O, B, H, Nq, Nk, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, key_bias=None, head_dim=0,

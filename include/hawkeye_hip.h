@@ -69,6 +69,14 @@ typedef struct hk_gemm_desc {
     int32_t res_dtype;  /* HK_DT_* of `residual` */
     int32_t scale_cols;
     float scale;
+    /* LayerNorm of A folded into the GEMM (vit.py:125-127: norm1 -> attn.qkv, norm2 -> mlp.fc1), both NULL when unused.
+     * With row_stats[m] = (mean_m, rstd_m) of row m of A (hk_row_stats), W holding gamma[k] * weight[n,k] rounded to
+     * bf16, col_c[n] = sum_k W[n,k] (of the rounded values) and bias[n] = linear bias + sum_k beta[k] * weight[n,k]:
+     *   C = act((rstd_m * (A . W^T)[m,n] - rstd_m * mean_m * col_c[n] + bias[n]) * colscale)
+     * = act((LayerNorm(A) . weight^T + linear bias) * colscale) without ever writing LayerNorm(A).
+     * Needs bias, bf16 output, no residual. */
+    const float* row_stats; /* [M][2] fp32 */
+    const float* col_c;     /* [N] fp32 */
 } hk_gemm_desc;
 
 int hk_gemm_bf16(const hk_gemm_desc* d, void* stream);
@@ -105,6 +113,12 @@ int hk_flash_attn_bf16(const hk_attn_desc* d, void* stream);
 int hk_layernorm(const void* x, int32_t in_dtype, const float* add, const float* gamma, const float* beta,
                  void* out_bf16, float* out_f32, const hk_rows* out_rows, int64_t rows, int32_t D, float eps,
                  void* stream);
+
+/* Row statistics of a bf16 matrix: stats[m] = (mean_m, 1 / sqrt(var_m + eps)), two-pass fp32 over the row held in
+ * registers (the same arithmetic as hk_layernorm's).  Feeds hk_gemm_desc.row_stats: the statistics half of
+ * nn.LayerNorm vit.py:108,114 when the normalisation itself is folded into the consuming GEMM.
+ * x [rows, D] plain, D % 8 == 0, D <= 2048; stats [rows][2] fp32. */
+int hk_row_stats(const void* x_bf16, float* stats, int64_t rows, int32_t D, float eps, void* stream);
 
 /* Patch gather for the per-frame 16x16 patch GEMM: clip [B,T,3,H,W] fp32 (the caller's
  * layout, tasks/test.py:490-492) -> A [B*T*(H/p)*(W/p), 3*p*p] bf16 with rows ordered (b,t,gy,gx) and

@@ -129,6 +129,39 @@ def test_gemm_split_tail_rows_match_a_plain_launch(M, N, K):
     assert torch.count_nonzero(big[:, rpb:]) == 0
 
 
+@pytest.mark.parametrize("M,N,K,act", [(512, 768, 1024, "none"), (66000, 1024, 1024, "gelu"), (300, 272, 128, "gelu"),
+                                         (100352 // 4 + 7, 3072, 1024, "none")])
+def test_gemm_with_folded_layernorm(M, N, K, act):
+    """hk_row_stats + row_stats/col_c epilogue == LayerNorm -> Linear (-> GELU) in fp32 (vit.py:125-127), on a residual
+    stream with a per-row offset and outlier channels (the mean term must cancel, not merely be small)."""
+    x = _rand((M, K), 21)
+    x = x * (1.0 + 4.0 * (torch.arange(K, device=DEV) % 97 == 0)) + _rand((M, 1), 22, 3.0)
+    x = x.to(torch.bfloat16)
+    w = _rand((N, K), 23, 0.05)
+    b = _rand((N,), 24)
+    g = 1.0 + 0.3 * _rand((K,), 25)
+    bt = 0.2 * _rand((K,), 26)
+    eps = 1e-6
+    st = ops.row_stats(x, eps)
+    xf = x.float()
+    mean = xf.mean(1)
+    rstd = (xf.var(1, unbiased=False) + eps).rsqrt()
+    assert torch.allclose(st[:, 0], mean, rtol=1e-5, atol=1e-6) and torch.allclose(st[:, 1], rstd, rtol=1e-5, atol=1e-7)
+    wf, cc, bf = ops.fold_layernorm(w, b, g, bt)
+    out = ops.linear(x, wf, bf, act=act, row_stats=st, col_c=cc, scale_cols=256 if act == "none" else 0, scale=0.25)
+    ref = torch.nn.functional.layer_norm(xf, (K,), g, bt, eps) @ w.t() + b
+    if act == "gelu":
+        ref = torch.nn.functional.gelu(ref)
+    else:
+        ref[:, :256] *= 0.25
+    # same error budget as LayerNorm (bf16 out) -> bf16 GEMM -> bf16 out
+    assert _rel(out.float(), ref) < 8e-3
+    # and it agrees with the unfolded pipeline of this library to the same budget
+    xn, _ = ops.layernorm(x, g, bt, eps)
+    plain = ops.linear(xn, w.to(torch.bfloat16), b, act=act, scale_cols=256 if act == "none" else 0, scale=0.25)
+    assert _rel(out.float(), plain.float()) < 8e-3
+
+
 def test_gemm_rejects_bad_shapes():
     x = _rand((8, 48), 1, dtype=torch.bfloat16)
     w = _rand((16, 48), 2, dtype=torch.bfloat16)

@@ -15,8 +15,15 @@ x = torch.randn(M, K, device=DEV).to(torch.bfloat16)
 w = (torch.randn(N, K, device=DEV) * 0.03).to(torch.bfloat16)
 b = torch.randn(N, device=DEV)
 out = torch.randn(M, N, device=DEV).to(torch.bfloat16)
+if mode.startswith("fold"):
+    g, bt = torch.ones(K, device=DEV), torch.zeros(K, device=DEV)
+    wf, cc, bf = ops.fold_layernorm(w.float(), b, g, bt)
+    st = torch.zeros((M + 255) // 256 * 256, 2, device=DEV)
+    ops.row_stats(x, 1e-6, out=st[:M])
 for _ in range(3):
-    if mode == "res16":
+    if mode.startswith("fold"):
+        ops.linear(x, wf, bf, act="gelu" if mode == "foldgelu" else "none", out=out, row_stats=st[:M], col_c=cc)
+    elif mode == "res16":
         ops.linear(x, w, b, residual=out, out_dtype=torch.bfloat16, out=out)
     else:
         ops.linear(x, w, b, act="gelu" if mode == "gelu" else "none", out=out)
