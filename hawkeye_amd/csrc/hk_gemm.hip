@@ -39,6 +39,7 @@ struct GemmParams {
     void* C;
     const float* row_stats;  // folded LayerNorm of A: [ceil256(M)][2] (mean, rstd) or null
     const float* col_c;      // with row_stats: [N] column sums of W
+    float* row_part;         // out: per row and 64-column group (sum, sum of squares) of C before rounding, or null
     int M, N, K;
     RowMap a, c, r;
     int64_t ldw;
@@ -102,6 +103,15 @@ __device__ __forceinline__ f32x4 gelu_erf4_bf16dst(const f32x4 v) {
 #endif
 }
 
+// Sum over the 8 lanes that share (lane >> 3): two quad permutes and a half-row mirror on the DPP path (every lane
+// ends up with the total; EXEC must be all ones).
+__device__ __forceinline__ float sum8_dpp(float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));
+    return x;
+}
+
 // 4 consecutive residual elements (fp32 or bf16) at element offset `off`
 __device__ __forceinline__ f32x4 load_res4(const GemmParams& p, int64_t off) {
     if (p.res_bf16) {
@@ -112,8 +122,8 @@ __device__ __forceinline__ f32x4 load_res4(const GemmParams& p, int64_t off) {
 }
 
 // One lane's 4 consecutive output columns of one row: bias, column scale, activation, residual, store.
-__device__ __forceinline__ void epi_store(const GemmParams& p, f32x4 v, const f32x4 bias, int n, int64_t coff,
-                                          int64_t roff, float rs, float rm) {
+__device__ __forceinline__ f32x4 epi_store(const GemmParams& p, f32x4 v, const f32x4 bias, int n, int64_t coff,
+                                           int64_t roff, float rs, float rm) {
     if (p.row_stats) {  // LayerNorm folded: rstd * acc + (bias' - rstd * mean * colsum)
         const f32x4 cc = *reinterpret_cast<const f32x4*>(p.col_c + n);
 #pragma unroll
@@ -132,6 +142,7 @@ __device__ __forceinline__ void epi_store(const GemmParams& p, f32x4 v, const f3
         o[1] = pack_bf16x2(v[2], v[3]);
         *reinterpret_cast<u32x2*>(reinterpret_cast<__bf16*>(p.C) + coff + n) = o;
     }
+    return v;
 }
 
 // Tile raster: groups of GM m-panels, inside a group m fastest, so any run of 32 consecutive tile ids
@@ -185,7 +196,8 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
 // The epilogue transposes each wave's 128x64 sub-tile through a private 4 KB LDS region above the
 // operand buffers (128 KB + 8 x 4 KB = all 160 KB of the CU) and writes whole row segments.
 // EPI selects the one epilogue this instantiation carries: 0 = bf16 out, no residual; 1 = fp32 staging
-// (fp32 out and/or fp32 residual); 2 = bf16 residual stream updated in place; 3 = 0 with the LayerNorm of A folded
+// (fp32 out and/or fp32 residual); 2 = bf16 residual stream updated in place (4 = 2 that also emits the row sums
+// the next LayerNorm needs, row_part); 3 = 0 with the LayerNorm of A folded
 // in (row_stats / col_c).  The folded form is its own instantiation because its extra live values cost the main loop
 // of EPI 0 ~20 % when they share one body (measured in situ), and its row statistics reach the epilogue without
 // registers or exposed latency: at the start of a tile every wave requests the (mean, rstd) pairs of
@@ -412,7 +424,7 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
             // possibly the output buffer itself) is read and the result stored as whole row segments, rounded
             // once.  The residual of round k+1 is requested before the stores of round k are issued, so no
             // round waits for a full memory round trip behind its predecessor's stores.
-            if (EPI == 2) {
+            if (EPI == 2 || EPI == 4) {
                 // bf16 residual stream updated in place: a lane owns 8 consecutive columns (16 B of bf16)
                 // of rows 8 it + (lane >> 3); two staged fp32 chunks + one 16-B residual load per store.
                 u32x4 rcur[2], rnxt[2];
@@ -443,13 +455,35 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
                         const f32x4 a = *reinterpret_cast<const f32x4*>(stg + row * 256 + (((2 * c8) ^ row) << 4));
                         const f32x4 b = *reinterpret_cast<const f32x4*>(stg + row * 256 + (((2 * c8 + 1) ^ row) << 4));
                         const int m = mw + rnd * 16 + row, n = nw + c8 * 8;
+                        const u32x4 r = rcur[it];
+                        const float v0 = a[0] + bf16_lo(r[0]), v1 = a[1] + bf16_hi(r[0]), v2 = a[2] + bf16_lo(r[1]),
+                                    v3 = a[3] + bf16_hi(r[1]), v4 = b[0] + bf16_lo(r[2]), v5 = b[1] + bf16_hi(r[2]),
+                                    v6 = b[2] + bf16_lo(r[3]), v7 = b[3] + bf16_hi(r[3]);
+                        if (EPI == 4) {
+                            // LayerNorm statistics of the updated residual stream, for the GEMM that consumes it with
+                            // the norm folded in: (sum, sum of squares) of this wave's 64 columns of the row
+                            float s1 = ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7));
+                            float s2 = v0 * v0;
+                            s2 = __builtin_fmaf(v1, v1, s2);
+                            s2 = __builtin_fmaf(v2, v2, s2);
+                            s2 = __builtin_fmaf(v3, v3, s2);
+                            s2 = __builtin_fmaf(v4, v4, s2);
+                            s2 = __builtin_fmaf(v5, v5, s2);
+                            s2 = __builtin_fmaf(v6, v6, s2);
+                            s2 = __builtin_fmaf(v7, v7, s2);
+                            s1 = sum8_dpp(s1);
+                            s2 = sum8_dpp(s2);
+                            if (c8 == 0 && m < p.M) {
+                                typedef __attribute__((ext_vector_type(2))) float f32x2s;
+                                *reinterpret_cast<f32x2s*>(p.row_part + ((int64_t)m * (p.N >> 6) + (nw >> 6)) * 2) = f32x2s{s1, s2};
+                            }
+                        }
                         if (m < p.M && n < p.N) {
-                            const u32x4 r = rcur[it];
                             u32x4 o;
-                            o[0] = pack_bf16x2(a[0] + bf16_lo(r[0]), a[1] + bf16_hi(r[0]));
-                            o[1] = pack_bf16x2(a[2] + bf16_lo(r[1]), a[3] + bf16_hi(r[1]));
-                            o[2] = pack_bf16x2(b[0] + bf16_lo(r[2]), b[1] + bf16_hi(r[2]));
-                            o[3] = pack_bf16x2(b[2] + bf16_lo(r[3]), b[3] + bf16_hi(r[3]));
+                            o[0] = pack_bf16x2(v0, v1);
+                            o[1] = pack_bf16x2(v2, v3);
+                            o[2] = pack_bf16x2(v4, v5);
+                            o[3] = pack_bf16x2(v6, v7);
                             *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(p.C) + p.c.off(m) + n) = o;
                         }
                     }
@@ -685,10 +719,28 @@ __global__ __launch_bounds__(WM* WN * 64) void hk_gemm_kernel(const GemmParams p
             rs = p.row_stats[2 * (int64_t)(m + p.m_off) + 1];
             rm = rs * mean;
         }
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int n = ncol + j * 16;
-            if (n < p.N) epi_store(p, acc[i][j], bias[j], n, coff, roff, rs, rm);
+            if (n < p.N) {
+                const f32x4 v = epi_store(p, acc[i][j], bias[j], n, coff, roff, rs, rm);
+                s1 += (v[0] + v[1]) + (v[2] + v[3]);
+                s2 = __builtin_fmaf(v[0], v[0], __builtin_fmaf(v[1], v[1], __builtin_fmaf(v[2], v[2], __builtin_fmaf(v[3], v[3], s2))));
+            }
+        }
+        if (TN == 64 && p.row_part) {
+            // row sums of this wave's 64 columns: the row's 4 lane groups (lane >> 4) hold 16 columns each; rows past
+            // M skipped above are skipped by all four of their lanes, so every lane read here is active
+            s1 += __shfl_xor(s1, 16);
+            s2 += __shfl_xor(s2, 16);
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (lane < 16) {
+                float* dst = p.row_part + ((int64_t)(m + p.m_off) * (p.N >> 6) + ((n0 + wn * TN) >> 6)) * 2;
+                dst[0] = s1;
+                dst[1] = s2;
+            }
         }
     }
 }
@@ -789,6 +841,9 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
                "hk_gemm_bf16: row_stats (folded LayerNorm) needs col_c and bias, bf16 output and no residual");
     HK_REQUIRE(((uintptr_t)d->row_stats % 16 == 0) && ((uintptr_t)d->col_c % 16 == 0),
                "hk_gemm_bf16: row_stats / col_c misaligned");
+    HK_REQUIRE(d->row_part == nullptr || (d->N % 128 == 0 && d->residual != nullptr && d->res_dtype == HK_DT_BF16 &&
+                                          d->out_dtype == HK_DT_BF16 && (uintptr_t)d->row_part % 8 == 0),
+               "hk_gemm_bf16: row_part needs N %% 128 == 0 and the bf16 residual-stream epilogue");
 
     GemmParams p;
     p.A = reinterpret_cast<const __bf16*>(d->A);
@@ -798,6 +853,7 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
     p.C = d->C;
     p.row_stats = d->row_stats;
     p.col_c = d->col_c;
+    p.row_part = d->row_part;
     p.M = d->M;
     p.N = d->N;
     p.K = d->K;
@@ -826,6 +882,7 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
     static const int variant = getenv("HK_GEMM_VARIANT") ? atoi(getenv("HK_GEMM_VARIANT")) : 1;
     auto small = [&](const GemmParams& q) {
         const long t128 = (long)((q.M + 127) / 128) * ((q.N + 127) / 128);
+        if (q.row_part && t128 < 384) return launch<128, 128, 2, 2, 4>(q, s);  // 64 columns per wave: the row_part granule
         if (t128 >= 384) return launch<128, 128, 2, 2, 2>(q, s);  // >= 1.5 workgroups per CU: 2 stages, 2 workgroups per CU
         if (t128 >= 128) return launch<128, 128, 2, 2, 4>(q, s);
         return launch<128, 64, 2, 2, 4>(q, s);
@@ -862,7 +919,7 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
         int rc;
         if (p.row_stats) rc = launch_pp<3>(p, s);
         else if (!p.out_f32 && !p.res) rc = launch_pp<0>(p, s);
-        else if (!p.out_f32 && p.res_bf16) rc = launch_pp<2>(p, s);
+        else if (!p.out_f32 && p.res_bf16) rc = p.row_part ? launch_pp<4>(p, s) : launch_pp<2>(p, s);
         else rc = launch_pp<1>(p, s);
         if (rc != HK_OK || tail.M == 0) return rc;
         return small(tail);

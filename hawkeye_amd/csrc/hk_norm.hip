@@ -181,6 +181,35 @@ __global__ __launch_bounds__(256) void hk_row_stats_kernel(const __bf16* xin, fl
     }
 }
 
+// (mean, rstd) from the (sum, sum of squares) partials of a GEMM epilogue (hk_gemm_desc.row_part): 8 lanes per row,
+// 16 bytes (two column groups) per lane and step, sums combined in float64.
+__global__ __launch_bounds__(256) void hk_row_stats_finalize_kernel(const float* part, float* stats, int64_t rows,
+                                                                   int groups, float eps) {
+    const int sub = threadIdx.x & 7;
+    int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;
+    const bool live = row < rows;
+    if (!live) row = rows - 1;          // keep every lane in the shuffles
+    const f32x4* pp = reinterpret_cast<const f32x4*>(part + row * groups * 2);
+    double s1 = 0.0, s2 = 0.0;
+    for (int g = sub; g < groups / 2; g += 8) {
+        const f32x4 v = pp[g];
+        s1 += (double)v[0] + (double)v[2];
+        s2 += (double)v[1] + (double)v[3];
+    }
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) {
+        s1 += __shfl_xor(s1, d);
+        s2 += __shfl_xor(s2, d);
+    }
+    if (live && sub == 0) {
+        const double D = 64.0 * groups;
+        const double mean = s1 / D;
+        const double var = fmax(s2 / D - mean * mean, 0.0);
+        stats[2 * row] = (float)mean;
+        stats[2 * row + 1] = rsqrtf((float)var + eps);
+    }
+}
+
 template <int NCH>
 __global__ __launch_bounds__(256) void hk_qf_embed_kernel(const float* query, const float* wemb, const float* pemb,
                                                           const int64_t* ids, const float* gamma, const float* beta,
@@ -315,6 +344,17 @@ extern "C" int hk_row_stats(const void* x_bf16, float* stats, int64_t rows, int3
     else if (n8 <= 2) hipLaunchKernelGGL((hk_row_stats_kernel<2>), grid, dim3(256), 0, s, xb, stats, rows, D, eps);
     else hipLaunchKernelGGL((hk_row_stats_kernel<4>), grid, dim3(256), 0, s, xb, stats, rows, D, eps);
     HK_CHECK_LAUNCH("hk_row_stats");
+    return HK_OK;
+}
+
+extern "C" int hk_row_stats_finalize(const float* part, float* stats, int64_t rows, int32_t groups, float eps,
+                                     void* stream) {
+    HK_REQUIRE(part && stats, "hk_row_stats_finalize: null pointer");
+    HK_REQUIRE(rows > 0 && groups > 0 && groups % 2 == 0, "hk_row_stats_finalize: bad shape rows=%ld groups=%d", (long)rows, groups);
+    HK_REQUIRE(((uintptr_t)part % 16 == 0) && ((uintptr_t)stats % 8 == 0), "hk_row_stats_finalize: misaligned operands");
+    hipLaunchKernelGGL(hk_row_stats_finalize_kernel, dim3((unsigned)((rows * 8 + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), part, stats, rows, groups, eps);
+    HK_CHECK_LAUNCH("hk_row_stats_finalize");
     return HK_OK;
 }
 

@@ -76,6 +76,9 @@ class HipEncoderEngine:
         # epilogue instead of a LayerNorm pass that writes its output); needs the bf16 residual stream the statistics
         # kernel reads.  HK_FOLD_LN=0 keeps the standalone LayerNorm (A/B aid).
         self.fold_ln = residual_dtype == torch.bfloat16 and os.environ.get("HK_FOLD_LN", "1") != "0"
+        # ... and the statistics themselves come out of the proj / fc2 epilogues that write the residual stream
+        # (hk_gemm_desc.row_part + hk_row_stats_finalize) instead of a pass over it.  HK_EPI_STATS=0: A/B aid.
+        self.epi_stats = os.environ.get("HK_EPI_STATS", "1") != "0"
         self.graph_max_frames = int(os.environ.get("HK_GRAPH_MAX_FRAMES", "64"))
 
     # ------------------------------------------------------------------ weights
@@ -211,6 +214,7 @@ class HipEncoderEngine:
             x = plan.buf("x", (M, D), self.residual_dtype, dev)
             xn = plan.buf("xn", (M, D), bf16, dev)
             rstat = plan.buf("rstat", ((M + 255) // 256 * 256, 2), f32, dev) if self.fold_ln else None   # whole 256-row tiles are read
+            rpart = plan.buf("rpart", (M, D // 64, 2), f32, dev) if self.fold_ln and self.epi_stats else None
             qkv = plan.buf("qkv", (M, 3 * D), bf16, dev)
             att = plan.buf("att", (M, D), bf16, dev)
             hid = plan.buf("hid", (M, D * cfg.mlp_ratio), bf16, dev)
@@ -249,7 +253,11 @@ class HipEncoderEngine:
             if self.fold_ln:
                 # vit.py:125 norm1 folded into attn.qkv: statistics of the residual stream, then the GEMM on x itself
                 self._tag = "vit.ln_stats"
-                plan.steps.append((self.lib.hk_row_stats, (P(x), P(rstat), M, D, cfg.vit_ln_eps), "hk_row_stats", self._tag))
+                if rpart is not None and i > 0:     # the previous block's fc2 epilogue left the row sums
+                    plan.steps.append((self.lib.hk_row_stats_finalize, (P(rpart), P(rstat), M, D // 64, cfg.vit_ln_eps),
+                                       "hk_row_stats_finalize", self._tag))
+                else:
+                    plan.steps.append((self.lib.hk_row_stats, (P(x), P(rstat), M, D, cfg.vit_ln_eps), "hk_row_stats", self._tag))
                 fold = dict(row_stats=P(rstat), col_c=P(w[o + "qkv.c"]))
             else:
                 self._tag = "vit.ln"
@@ -261,11 +269,16 @@ class HipEncoderEngine:
             self._attn(plan, P(qkv), P(qkv) + 2 * D, P(qkv) + 4 * D, P(att), B, Hv, N, N,
                        3 * D, 3 * D, 3 * D, D, N * 3 * D, N * 3 * D, N * 3 * D, N * D)
             self._tag = "vit.proj"
+            pkw = dict(row_part=P(rpart)) if rpart is not None else {}
             self._gemm(plan, P(att), w[o + "proj.w"], P(x), M, D, D, bias=P(w[o + "proj.b"]), residual=P(x),
-                       a_rows=plain(D), c_rows=plain(D), r_rows=plain(D), **rkw)
+                       a_rows=plain(D), c_rows=plain(D), r_rows=plain(D), **rkw, **pkw)
             if self.fold_ln:
                 self._tag = "vit.ln_stats"
-                plan.steps.append((self.lib.hk_row_stats, (P(x), P(rstat), M, D, cfg.vit_ln_eps), "hk_row_stats", self._tag))
+                if rpart is not None:
+                    plan.steps.append((self.lib.hk_row_stats_finalize, (P(rpart), P(rstat), M, D // 64, cfg.vit_ln_eps),
+                                       "hk_row_stats_finalize", self._tag))
+                else:
+                    plan.steps.append((self.lib.hk_row_stats, (P(x), P(rstat), M, D, cfg.vit_ln_eps), "hk_row_stats", self._tag))
                 fold = dict(row_stats=P(rstat), col_c=P(w[o + "fc1.c"]))
             else:
                 self._tag = "vit.ln"
@@ -275,8 +288,10 @@ class HipEncoderEngine:
                        bias=P(w[o + "fc1.b"]), a_rows=plain(D), c_rows=plain(D * cfg.mlp_ratio),
                        act=L.HK_ACT_GELU_ERF, **fold)
             self._tag = "vit.fc2"
+            if i == cfg.run_depth - 1:
+                pkw = {}                            # followed by vision_layernorm, which is not folded
             self._gemm(plan, P(hid), w[o + "fc2.w"], P(x), M, D, D * cfg.mlp_ratio, bias=P(w[o + "fc2.b"]),
-                       residual=P(x), a_rows=plain(D * cfg.mlp_ratio), c_rows=plain(D), r_rows=plain(D), **rkw)
+                       residual=P(x), a_rows=plain(D * cfg.mlp_ratio), c_rows=plain(D), r_rows=plain(D), **rkw, **pkw)
         # vision_layernorm (hawkeye_it.py:234) then the K/V projections of every cross layer at once
         self._tag = "vision_layernorm"
         self._ln(plan, P(x), xf32, w["vln.g"], w["vln.b"], P(xn), None, M, D, cfg.vision_ln_eps)

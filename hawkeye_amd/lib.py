@@ -31,7 +31,7 @@ class HkGemmDesc(C.Structure):
         ("a_rows", HkRows), ("ldw", C.c_int64), ("c_rows", HkRows), ("r_rows", HkRows),
         ("act", C.c_int32), ("out_dtype", C.c_int32), ("res_dtype", C.c_int32), ("scale_cols", C.c_int32),
         ("scale", C.c_float),
-        ("row_stats", C.c_void_p), ("col_c", C.c_void_p),
+        ("row_stats", C.c_void_p), ("col_c", C.c_void_p), ("row_part", C.c_void_p),
     ]
 
 
@@ -75,6 +75,7 @@ SYMBOLS = {
     "hk_layernorm": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.POINTER(HkRows), C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
     "hk_row_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
+    "hk_row_stats_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
     "hk_patchify_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_void_p]),
     "hk_patchify_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

@@ -31,7 +31,7 @@ def _need(t: torch.Tensor, dtype, name: str):
 
 def gemm_desc(A, W, C_out, M, N, K, *, bias=None, residual=None, a_rows: Rows, c_rows: Rows,
               r_rows: Rows = (0, 0, 0), ldw=None, act=L.HK_ACT_NONE, out_f32=False, res_bf16=False,
-              scale_cols=0, scale=1.0, row_stats=None, col_c=None) -> L.HkGemmDesc:
+              scale_cols=0, scale=1.0, row_stats=None, col_c=None, row_part=None) -> L.HkGemmDesc:
     """Raw-pointer descriptor; A/W/C_out/bias/residual (and row_stats/col_c: LayerNorm of A folded into the GEMM,
     see include/hawkeye_hip.h) are integer device addresses."""
     d = L.HkGemmDesc()
@@ -46,7 +46,7 @@ def gemm_desc(A, W, C_out, M, N, K, *, bias=None, residual=None, a_rows: Rows, c
     d.res_dtype = L.HK_DT_BF16 if res_bf16 else L.HK_DT_F32
     d.scale_cols = scale_cols
     d.scale = scale
-    d.row_stats, d.col_c = row_stats, col_c
+    d.row_stats, d.col_c, d.row_part = row_stats, col_c, row_part
     return d
 
 
@@ -57,7 +57,8 @@ def run_gemm(d: L.HkGemmDesc):
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
            residual: Optional[torch.Tensor] = None, act: str = "none", out_dtype=torch.bfloat16,
            scale_cols: int = 0, scale: float = 1.0, out: Optional[torch.Tensor] = None,
-           row_stats: Optional[torch.Tensor] = None, col_c: Optional[torch.Tensor] = None) -> torch.Tensor:
+           row_stats: Optional[torch.Tensor] = None, col_c: Optional[torch.Tensor] = None,
+           row_part: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = act((x @ w.T + bias) * colscale) + residual; x [M,K] bf16, w [N,K] bf16.
     row_stats [M,2] fp32 + col_c [N] fp32: LayerNorm of x folded into the GEMM (w, bias prepared by fold_layernorm)."""
     _need(x, torch.bfloat16, "x")
@@ -88,6 +89,11 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         if tuple(row_stats.shape) != (M, 2) or tuple(col_c.shape) != (N,) or not row_stats.is_contiguous():
             raise RuntimeError("linear: row_stats must be [M,2] and col_c [N]")
         d.row_stats, d.col_c = row_stats.data_ptr(), col_c.data_ptr()
+    if row_part is not None:   # out: [M, N/64, 2] (sum, sum of squares) of the result rows, for the next LayerNorm
+        _need(row_part, torch.float32, "row_part")
+        if tuple(row_part.shape) != (M, N // 64, 2) or not row_part.is_contiguous():
+            raise RuntimeError("linear: row_part must be a contiguous [M, N/64, 2] tensor")
+        d.row_part = row_part.data_ptr()
     run_gemm(d)
     return out
 
@@ -101,6 +107,17 @@ def row_stats(x: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -
     if out is None:
         out = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
     L.check(L.load().hk_row_stats(x.data_ptr(), out.data_ptr(), rows, D, eps, _stream()), "hk_row_stats")
+    return out
+
+
+def row_stats_finalize(part: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[rows, groups, 2] partial sums written by linear(..., row_part=) -> fp32 [rows, 2] (mean, rstd)."""
+    _need(part, torch.float32, "part")
+    rows, groups, _ = part.shape
+    if out is None:
+        out = torch.empty((rows, 2), dtype=torch.float32, device=part.device)
+    L.check(L.load().hk_row_stats_finalize(part.data_ptr(), out.data_ptr(), rows, groups, eps, _stream()),
+            "hk_row_stats_finalize")
     return out
 
 

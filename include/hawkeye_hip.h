@@ -75,8 +75,13 @@ typedef struct hk_gemm_desc {
      *   C = act((rstd_m * (A . W^T)[m,n] - rstd_m * mean_m * col_c[n] + bias[n]) * colscale)
      * = act((LayerNorm(A) . weight^T + linear bias) * colscale) without ever writing LayerNorm(A).
      * Needs bias, bf16 output, no residual. */
-    const float* row_stats; /* [M][2] fp32 */
+    const float* row_stats; /* [ceil(M / 256) * 256][2] fp32: whole 256-row tiles are read (rows >= M: any value) */
     const float* col_c;     /* [N] fp32 */
+    /* Optional output for the LayerNorm that FOLLOWS this GEMM (vit.py:126-127: proj / fc2 + residual, then norm2 /
+     * the next block's norm1): row_part[m][g] = (sum, sum of squares) over columns 64 g .. 64 g + 63 of row m of C,
+     * taken on the fp32 values before the output rounding; hk_row_stats_finalize turns them into (mean, rstd).
+     * Needs N % 128 == 0 and the bf16 in-place residual epilogue; NULL when unused. */
+    float* row_part;        /* [M][N / 64][2] fp32 */
 } hk_gemm_desc;
 
 int hk_gemm_bf16(const hk_gemm_desc* d, void* stream);
@@ -119,6 +124,10 @@ int hk_layernorm(const void* x, int32_t in_dtype, const float* add, const float*
  * nn.LayerNorm vit.py:108,114 when the normalisation itself is folded into the consuming GEMM.
  * x [rows, D] plain, D % 8 == 0, D <= 2048; stats [rows][2] fp32. */
 int hk_row_stats(const void* x_bf16, float* stats, int64_t rows, int32_t D, float eps, void* stream);
+
+/* stats[m] = (mean, rstd) from the per-group sums a GEMM left in hk_gemm_desc.row_part: part [rows][groups][2],
+ * D = 64 * groups columns per row; sums combined in float64, var = E[x^2] - mean^2 clamped at 0. */
+int hk_row_stats_finalize(const float* part, float* stats, int64_t rows, int32_t groups, float eps, void* stream);
 
 /* Patch gather for the per-frame 16x16 patch GEMM: clip [B,T,3,H,W] fp32 (the caller's
  * layout, tasks/test.py:490-492) -> A [B*T*(H/p)*(W/p), 3*p*p] bf16 with rows ordered (b,t,gy,gx) and

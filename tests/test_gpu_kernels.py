@@ -162,6 +162,32 @@ def test_gemm_with_folded_layernorm(M, N, K, act):
     assert _rel(out.float(), plain.float()) < 8e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 1024, 256), (100352 // 2 + 3, 1024, 1024), (300, 256, 128), (66000, 1024, 128)])
+def test_gemm_row_part_feeds_the_next_layernorm(M, N, K):
+    """row_part of the in-place residual epilogue (persistent kernel, its split tail and the small kernel) ->
+    hk_row_stats_finalize == the statistics hk_row_stats takes from the stored bf16 rows, up to the bf16 rounding of
+    the rows themselves (the sums are taken before it)."""
+    x = _rand((M, K), 31, dtype=torch.bfloat16)
+    w = _rand((N, K), 32, 0.05, dtype=torch.bfloat16)
+    b = _rand((N,), 33)
+    res = (_rand((M, N), 34) * 2.0 + _rand((M, 1), 35, 1.5)).to(torch.bfloat16)
+    ref = x.float() @ w.float().t() + b + res.float()
+    part = torch.full((M, N // 64, 2), float("nan"), device=DEV)
+    out = res.clone()
+    ops.linear(x, w, b, residual=out, out_dtype=torch.bfloat16, out=out, row_part=part)
+    plain = res.clone()
+    ops.linear(x, w, b, residual=plain, out_dtype=torch.bfloat16, out=plain)
+    assert torch.equal(out, plain)                      # the output itself is untouched by the extra sums
+    g = ref.view(M, N // 64, 64)
+    assert torch.allclose(part[:, :, 0], g.sum(2), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(part[:, :, 1], (g * g).sum(2), rtol=1e-4, atol=1e-3)
+    st = ops.row_stats_finalize(part, 1e-6)
+    st_ref = ops.row_stats(out, 1e-6)
+    # a stored element is off by up to 2^-9 |x| from the value that was summed; the mean of N of them by ~that / sqrt(N)
+    assert torch.allclose(st[:, 0], st_ref[:, 0], atol=4e-3 * float(ref.abs().max()) / math.sqrt(N))
+    assert torch.allclose(st[:, 1], st_ref[:, 1], rtol=2e-3)
+
+
 def test_gemm_rejects_bad_shapes():
     x = _rand((8, 48), 1, dtype=torch.bfloat16)
     w = _rand((16, 48), 2, dtype=torch.bfloat16)
