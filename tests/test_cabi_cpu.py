@@ -32,9 +32,10 @@ def test_version_and_arch():
 
 
 def test_struct_layout_matches_header():
-    # hk_rows: 3 x int64; hk_gemm_desc: 5 ptr, 3 int32 (+pad), rows, int64, rows, rows, 3 int32 + float
+    # hk_rows: 3 x int64; hk_gemm_desc: 5 ptr, 3 int32 (+pad), rows, int64, rows, rows, 4 int32 + float (+pad),
+    # then row_stats, col_c, row_part
     assert C.sizeof(L.HkRows) == 24
-    assert C.sizeof(L.HkGemmDesc) == 5 * 8 + 16 + 24 + 8 + 24 + 24 + 24   # 4 int32 + float, padded to 8
+    assert C.sizeof(L.HkGemmDesc) == 5 * 8 + 16 + 24 + 8 + 24 + 24 + 24 + 3 * 8   # 4 int32 + float, padded to 8
     assert C.sizeof(L.HkAttnDesc) == 5 * 8 + 16 + 8 * 8 + 8   # + head_dim, causal
 
 
