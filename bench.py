@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--lt", type=int, default=32, help="instruction tokens")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-insitu", action="store_true", help="skip the per-kernel in-situ timing and the MFMA probe (PMC passes)")
     ap.add_argument("--force-gather", action="store_true", help="run the output all_gather even with one rank (plumbing test)")
     args = ap.parse_args()
 
@@ -128,13 +129,17 @@ def main():
         achieved = fl * B / step_s / 1e12
         # HBM-side bytes per step from the committed rocprofv3 PMC passes (profiles/r01c_hbm_traffic.txt);
         # PMC collection needs the profiler, so the live run quotes the profiled figure for this workload
-        traffic = None
+        tj = {}
         try:
             tj = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
-            if tj.get("workload") == f"B={B} T={T} Lt={Lt}":
-                traffic = tj["bytes_per_step"]
-        except (OSError, ValueError, KeyError):
-            traffic = None
+            if tj.get("workload") != f"B={B} T={T} Lt={Lt}":
+                tj = {}
+        except (OSError, ValueError):
+            tj = {}
+        step_roof = {"kernel": "encode_img step (all launches of one call)", "achieved": round(achieved, 2),
+                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                     "traffic": tj.get("bytes_per_step"), "gflop_per_clip": round(fl / 1e9, 1),
+                     "device_ms_per_step": round(step_s * 1e3, 3)}
         res = {
             "metric": "encode_img clips/s (UMT-L/16+QFormer,16f@224)", "value": round(value, 3), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -144,40 +149,52 @@ def main():
                        "clips_per_gpu": B, "frames": T, "tokens_per_clip": T * cfg.patches_per_frame,
                        "vit_blocks": cfg.run_depth, "parallelism": f"clip-sharded x{world}",
                        "output_all_gather": bool(gather)},
-            "roofline": {"bound": "mfma", "kernel": "encode_img step (all launches of one call)",
-                         "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                         "gflop_per_clip": round(fl / 1e9, 1), "device_ms_per_step": round(step_s * 1e3, 3)},
+            "roofline": dict(step_roof, bound="mfma", step=step_roof),
         }
-        # per-kernel roofline, in situ: one HIP event pair around every launch of 3 more calls (same stream and
-        # order as the timed steps); algorithmic flops per launch from SURVEY.md §8d's formula terms
-        N_, D_, R_ = T * cfg.patches_per_frame, cfg.encoder_embed_dim, B * T * cfg.patches_per_frame
-        kflops = {"vit.qkv": 2.0 * R_ * D_ * 3 * D_, "vit.attn": 4.0 * B * N_ * N_ * D_, "vit.proj": 2.0 * R_ * D_ * D_,
-                  "vit.fc1_gelu": 2.0 * R_ * D_ * 4 * D_, "vit.fc2": 2.0 * R_ * D_ * 4 * D_,
-                  "vit.patch_embed": 2.0 * R_ * cfg.patch_k * D_,
-                  "qformer.cross_kv": 2.0 * R_ * D_ * 2 * cfg.qf_hidden * 6}
-        eng = model.sync_engine()
-        table = model._table(T == 1, N_, dev)
-        prof = eng.profile(image, ids, mask, table, reps=3)
-        kern, tot_us = {}, sum(n * us for n, us in prof.values())
-        for tag, (n, us) in sorted(prof.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
-            e = {"launches": n, "us": round(us, 1), "share": round(n * us / tot_us, 4)}
-            if tag in kflops:
-                e["tflops"] = round(kflops[tag] / us / 1e6, 1)
-                e["frac"] = round(kflops[tag] / us / 1e6 / PEAK_BF16_TFLOPS, 4)
-            elif tag in ("vit.ln", "vision_layernorm", "vit.ln_stats"):
-                nbytes = R_ * D_ * ((2 if tag != "vit.ln_stats" else 0) + (2 if eng.residual_dtype == torch.bfloat16 else 4))
-                e["tb_s"] = round(nbytes / us / 1e6, 2)
-                e["frac_hbm"] = round(nbytes / us / 1e6 / 8.0, 4)
-            kern[tag] = e
-        dom = next(iter(kern))
-        res["roofline"]["dominant_kernel"] = dict(kern[dom], tag=dom)
-        res["roofline"]["kernels"] = kern
-        # register-resident MFMA probe on this chip: what the silicon sustains with random / zero data
-        mp = {"16x16x32_random": round(ops.mfma_probe_tflops(0), 1), "16x16x32_zeros": round(ops.mfma_probe_tflops(0, zeros=True), 1),
-              "32x32x16_random": round(ops.mfma_probe_tflops(1), 1)}
-        res["roofline"]["measured_mfma_peak"] = mp
-        res["roofline"]["frac_of_measured_peak"] = round(achieved / max(mp["16x16x32_random"], 1e-9), 4)
+        if not args.no_insitu:
+            # Dominant kernel, in situ: one HIP event pair around every launch of 3 more calls (same stream and order as
+            # the timed steps); algorithmic flops per launch from SURVEY.md 8d's formula terms; roofline.achieved is that
+            # kernel's flops per launch / its average launch duration, roofline.step the whole launch sequence.
+            N_, D_, R_ = T * cfg.patches_per_frame, cfg.encoder_embed_dim, B * T * cfg.patches_per_frame
+            kflops = {"vit.qkv": 2.0 * R_ * D_ * 3 * D_, "vit.attn": 4.0 * B * N_ * N_ * D_, "vit.proj": 2.0 * R_ * D_ * D_,
+                      "vit.fc1_gelu": 2.0 * R_ * D_ * 4 * D_, "vit.fc2": 2.0 * R_ * D_ * 4 * D_,
+                      "vit.patch_embed": 2.0 * R_ * cfg.patch_k * D_,
+                      "qformer.cross_kv": 2.0 * R_ * D_ * 2 * cfg.qf_hidden * 6}
+            kname = {"vit.attn": "hk_attn_kernel<false, 1, 3, 1>", "vit.qkv": "hk_gemm_pp_kernel<3>",
+                     "vit.fc1_gelu": "hk_gemm_pp_kernel<3>", "vit.fc2": "hk_gemm_pp_kernel<4>", "vit.proj": "hk_gemm_pp_kernel<4>"}
+            eng = model.sync_engine()
+            table = model._table(T == 1, N_, dev)
+            prof = eng.profile(image, ids, mask, table, reps=3)
+            kern, tot_us = {}, sum(n * us for n, us in prof.values())
+            for tag, (n, us) in sorted(prof.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+                e = {"launches": n, "us": round(us, 1), "share": round(n * us / tot_us, 4)}
+                if tag in kflops:
+                    e["tflops"] = round(kflops[tag] / us / 1e6, 1)
+                    e["frac"] = round(kflops[tag] / us / 1e6 / PEAK_BF16_TFLOPS, 4)
+                elif tag in ("vit.ln", "vision_layernorm", "vit.ln_stats"):
+                    nbytes = R_ * D_ * ((2 if tag != "vit.ln_stats" else 0) + (2 if eng.residual_dtype == torch.bfloat16 else 4))
+                    if tag == "vit.ln_stats" and eng.epi_stats:
+                        nbytes = R_ * (D_ // 64) * 8      # the epilogue partial sums the finalize pass reads
+                    e["tb_s"] = round(nbytes / us / 1e6, 2)
+                    e["frac_hbm"] = round(nbytes / us / 1e6 / 8.0, 4)
+                kern[tag] = e
+            dom = next(t for t in kern if t in kflops)
+            ktraffic = None
+            for k, v in (tj.get("per_kernel") or {}).items():      # keys: "<kernel> [<workgroups> wg]"
+                if k.startswith(kname.get(dom, "?")) and v.get("launches_per_step") == kern[dom]["launches"]:
+                    ktraffic = v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]
+            res["roofline"].update({
+                "kernel": f"{kname.get(dom, dom)} ({dom}, {kern[dom]['launches']} launches per step, {kern[dom]['share'] * 100:.1f} % of it)",
+                "achieved": kern[dom]["tflops"], "frac": kern[dom]["frac"], "traffic": ktraffic,
+                "flop_per_launch": kflops[dom], "us_per_launch": kern[dom]["us"]})
+            for k in ("gflop_per_clip", "device_ms_per_step"):
+                res["roofline"].pop(k, None)
+            res["roofline"]["kernels"] = kern
+            # register-resident MFMA probe on this chip: what the silicon sustains with random / zero data
+            mp = {"16x16x32_random": round(ops.mfma_probe_tflops(0), 1), "16x16x32_zeros": round(ops.mfma_probe_tflops(0, zeros=True), 1),
+                  "32x32x16_random": round(ops.mfma_probe_tflops(1), 1)}
+            res["roofline"]["measured_mfma_peak"] = mp
+            res["roofline"]["step"] = dict(step_roof, frac_of_measured_peak=round(achieved / max(mp["16x16x32_random"], 1e-9), 4))
         if not args.no_cpu_baseline:
             base, ref = cpu_baseline(sd, T, Lt, seed)
             res["cpu_baseline"] = base
