@@ -254,12 +254,21 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
             // register i of st[kt] <-> key t*64 + 32 kt + (i & 3) + 8 (i >> 2) + 4 h
             if (HAS_BIAS) {
                 const float* kb = p.key_bias + (int64_t)b * p.Nk;
+                typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int key = t * KT + 32 * kt + (i & 3) + 8 * (i >> 2) + 4 * h;
-                        if (key < p.Nk) st[kt][i] += kb[key] * HK_LOG2E;
+                    for (int g = 0; g < 4; ++g) {
+                        const int key0 = t * KT + 32 * kt + 8 * g + 4 * h;  // registers 4g..4g+3 <-> keys key0..key0+3
+                        if (!RAGGED) {   // whole tile exists: one 16-byte load per four keys
+                            const f32x4u v = *reinterpret_cast<const f32x4u*>(kb + key0);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) st[kt][4 * g + e] = __builtin_fmaf(v[e], HK_LOG2E, st[kt][4 * g + e]);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (key0 + e < p.Nk) st[kt][4 * g + e] = __builtin_fmaf(kb[key0 + e], HK_LOG2E, st[kt][4 * g + e]);
+                        }
                     }
             }
             if (RAGGED) {  // keys >= Nk do not exist
@@ -485,7 +494,10 @@ extern "C" int hk_flash_attn_bf16(const hk_attn_desc* d, void* stream) {
     static const int ldr = getenv("HK_ATTN_LOADER") ? atoi(getenv("HK_ATTN_LOADER")) : 1;
     const dim3 grid((unsigned)nwg), block(256);
 #define HK_ATTN_LAUNCH(BIAS, M, O, L) hipLaunchKernelGGL((hk_attn_kernel<BIAS, M, O, L>), grid, block, 0, s, p)
-    if (d->key_bias) HK_ATTN_LAUNCH(true, 0, 1, 0);
+    // key-bias (Q-Former text mask) launches: the tuned loader / softmax form too; HK_ATTN_BIAS=0: the first-round variant
+    static const int bvar = getenv("HK_ATTN_BIAS") ? atoi(getenv("HK_ATTN_BIAS")) : 1;
+    if (d->key_bias && bvar == 0) HK_ATTN_LAUNCH(true, 0, 1, 0);
+    else if (d->key_bias) HK_ATTN_LAUNCH(true, 1, 2, 1);
     else if (ldr == 1 && mode == 1 && occ == 3) HK_ATTN_LAUNCH(false, 1, 3, 1);
     else if (ldr == 1 && mode == 1) HK_ATTN_LAUNCH(false, 1, 2, 1);
     else if (ldr == 1 && occ == 3) HK_ATTN_LAUNCH(false, 0, 3, 1);

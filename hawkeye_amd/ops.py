@@ -88,6 +88,10 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         _need(col_c, torch.float32, "col_c")
         if tuple(row_stats.shape) != (M, 2) or tuple(col_c.shape) != (N,) or not row_stats.is_contiguous():
             raise RuntimeError("linear: row_stats must be [M,2] and col_c [N]")
+        # the persistent kernel fetches the statistics of whole 256-row tiles: the allocation must cover them
+        have = row_stats.untyped_storage().nbytes() - row_stats.storage_offset() * 4
+        if have < (M + 255) // 256 * 256 * 8:
+            raise RuntimeError("linear: row_stats storage must extend to a multiple of 256 rows (ops.row_stats pads it)")
         d.row_stats, d.col_c = row_stats.data_ptr(), col_c.data_ptr()
     if row_part is not None:   # out: [M, N/64, 2] (sum, sum of squares) of the result rows, for the next LayerNorm
         _need(row_part, torch.float32, "row_part")
@@ -104,8 +108,8 @@ def row_stats(x: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -
     if x.dim() != 2 or not x.is_contiguous():
         raise RuntimeError("row_stats: x must be a contiguous [rows, D] matrix")
     rows, D = x.shape
-    if out is None:
-        out = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+    if out is None:   # padded to whole 256-row tiles (what a folded GEMM may read), returned as the [rows, 2] view
+        out = torch.zeros(((rows + 255) // 256 * 256, 2), dtype=torch.float32, device=x.device)[:rows]
     L.check(L.load().hk_row_stats(x.data_ptr(), out.data_ptr(), rows, D, eps, _stream()), "hk_row_stats")
     return out
 
@@ -115,7 +119,7 @@ def row_stats_finalize(part: torch.Tensor, eps: float, out: Optional[torch.Tenso
     _need(part, torch.float32, "part")
     rows, groups, _ = part.shape
     if out is None:
-        out = torch.empty((rows, 2), dtype=torch.float32, device=part.device)
+        out = torch.zeros(((rows + 255) // 256 * 256, 2), dtype=torch.float32, device=part.device)[:rows]
     L.check(L.load().hk_row_stats_finalize(part.data_ptr(), out.data_ptr(), rows, groups, eps, _stream()),
             "hk_row_stats_finalize")
     return out
