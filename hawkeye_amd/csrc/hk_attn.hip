@@ -35,6 +35,7 @@ struct AttnParams {
     int nqb;
     int prio;     // staged wave priority inside a tile (see the kernel); 0 = off (A/B aid)
     int o_vec16;  // O rows 16-byte aligned: the epilogue may store whole 128-byte row segments
+    unsigned long long* stamp;  // diagnostic build (-DHK_ATTN_STAMP) only: per-wave phase cycle totals
 };
 
 constexpr int QB = 128;   // query rows per workgroup
@@ -61,6 +62,25 @@ __device__ __forceinline__ float half_swap_sum(float x) {
     float a, b;
     half_swap(x, a, b);
     return a + b;
+}
+
+// LDS-DMA with a scalar base: address = SGPR pair + one 32-bit per-lane byte offset (no 64-bit vector address
+// arithmetic per piece).  Inline asm: the builtin always takes a 64-bit vector address.  lds = the wave's destination.
+__device__ __forceinline__ void glds16_s(const void* sbase, uint32_t voff, const void* lds) {
+    const uint32_t la = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :
+                 : "v"(voff), "s"(sbase), "s"(la)
+                 : "memory");
+}
+// The same with a 64-bit per-lane address (ragged last tile).  The pipelined kernel issues every LDS-DMA through these two
+// helpers, so the compiler itself never holds a value in M0 there (M0 is reserved and cannot be named as a clobber).
+__device__ __forceinline__ void glds16_v(const void* vaddr, const void* lds) {
+    const uint32_t la = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :
+                 : "v"(vaddr), "s"(la)
+                 : "memory");
 }
 
 template <bool HAS_BIAS, int MODE, int OCC, int LOADER>
@@ -152,16 +172,30 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
         if ((tile + 1) * KT <= p.Nk) {
             const char* kt_ = kU + (int64_t)tile * 2 * k32b;
             const char* vt_ = vU + (int64_t)tile * 2 * v32b;
-            glds16(kt_ + klane, ks);
-            glds16(kt_ + k32b + klane, ks + 32 * 128);
-            glds16(vt_ + vlane, vs);
-            glds16(vt_ + v32b + vlane, vs + 32 * 128);
+            if constexpr (HAS_BIAS) {   // that instantiation is short of SGPRs: the builtin (vector address) form throughout
+                glds16(kt_ + klane, ks);
+                glds16(kt_ + k32b + klane, ks + 32 * 128);
+                glds16(vt_ + vlane, vs);
+                glds16(vt_ + v32b + vlane, vs + 32 * 128);
+            } else {
+                glds16_s(kt_, klane, ks);
+                glds16_s(kt_ + k32b, klane, ks + 32 * 128);
+                glds16_s(vt_, vlane, vs);
+                glds16_s(vt_ + v32b, vlane, vs + 32 * 128);
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int key = min(tile * KT + i * 32 + lkey, p.Nk - 1);
-                glds16(p.K + (int64_t)b * p.bsk + head * 64 + ck * 8 + (int64_t)key * p.ldk, ks + i * 32 * 128);
-                glds16(p.V + (int64_t)b * p.bsv + head * 64 + cv * 8 + (int64_t)key * p.ldv, vs + i * 32 * 128);
+                const __bf16* ka = p.K + (int64_t)b * p.bsk + head * 64 + ck * 8 + (int64_t)key * p.ldk;
+                const __bf16* va = p.V + (int64_t)b * p.bsv + head * 64 + cv * 8 + (int64_t)key * p.ldv;
+                if constexpr (HAS_BIAS) {
+                    glds16(ka, ks + i * 32 * 128);
+                    glds16(va, vs + i * 32 * 128);
+                } else {
+                    glds16_v(ka, ks + i * 32 * 128);
+                    glds16_v(va, vs + i * 32 * 128);
+                }
             }
         }
     };
@@ -189,9 +223,23 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) ot[dt][i] = 0.f;
     float m_run = 0.f, l_run = 0.f;  // every stored quantity is relative to m_run
+    // LOADER 2: -m_run kept in 16 registers as the srcC of the first MFMA of each chain, rebuilt only when m_run moves
+    f32x16 cneg;
+    auto set_cneg = [&]() {
+        typedef __attribute__((ext_vector_type(2))) float f32x2;
+        const f32x2 negm2 = {-m_run, -m_run};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            f32x2 c2;
+            asm volatile("v_mov_b64 %0, %1" : "=v"(c2) : "v"(negm2));
+            cneg[2 * j] = c2[0];
+            cneg[2 * j + 1] = c2[1];
+        }
+    };
+    if (LOADER == 2) set_cneg();
 
     const int NT = (p.Nk + KT - 1) / KT;
-    if (LOADER == 1) {
+    if (LOADER >= 1) {
         gdma(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
@@ -220,7 +268,7 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
         constexpr bool RAGGED = decltype(ragged_c)::value;
         constexpr int cur = decltype(cur_c)::value;
         if (t + 1 < NT) {
-            if (LOADER == 1) gdma(t + 1, cur ^ 1); else gload(t + 1);
+            if (LOADER >= 1) gdma(t + 1, cur ^ 1); else gload(t + 1);
         }
         const char* ks = smem + cur * (2 * KT * 128);
         const char* vs = ks + KT * 128;
@@ -234,20 +282,23 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
             typedef __attribute__((ext_vector_type(2))) float f32x2;
             const f32x2 negm2 = {-m_run, -m_run};
             f32x16 cinit;
+            if (LOADER == 2) {
+                cinit = cneg;
+            } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                f32x2 c2;
-                asm volatile("v_mov_b64 %0, %1" : "=v"(c2) : "v"(negm2));
-                cinit[2 * j] = c2[0];
-                cinit[2 * j + 1] = c2[1];
+                for (int j = 0; j < 8; ++j) {
+                    f32x2 c2;
+                    asm volatile("v_mov_b64 %0, %1" : "=v"(c2) : "v"(negm2));
+                    cinit[2 * j] = c2[0];
+                    cinit[2 * j + 1] = c2[1];
+                }
             }
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
-                st[kt] = cinit;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + kt * 32 * 128 + koff[s]);
-                    st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[kt], 0, 0, 0);
+                    st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s == 0 ? cinit : st[kt], 0, 0, 0);
                 }
             }
             if (p.prio) __builtin_amdgcn_s_setprio(0);
@@ -293,6 +344,7 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
             const float delta = FIRST ? mx : fmaxf(mx, 0.f);
             const float alpha = FIRST ? 0.f : __builtin_amdgcn_exp2f(-delta);
             m_run += delta;
+            if (LOADER == 2) set_cneg();
             l_run *= alpha;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
@@ -369,7 +421,7 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
         }
 
         if (p.prio) __builtin_amdgcn_s_setprio(0);
-        if (LOADER == 1) {
+        if (LOADER >= 1) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else if (t + 1 < NT) {
             lstore(cur ^ 1);
@@ -444,6 +496,403 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Software-pipelined variant for the ViT shape (no key bias): one loop iteration runs the softmax and P.V of tile t
+// and, interleaved instruction by instruction with that softmax, the Q.K^T of tile t + 1 -- so a wave's own exp /
+// convert VALU work issues in the shadow of its own MFMAs instead of waiting for another wave to cover it.
+//   iteration t:  DMA K(t+2), V(t+1)  |  8 x { MFMA S(t+1) ; 4 exp2 + 2 cvt_pk + 2 dot2 of S(t) }  |  overflow check
+//                 |  8 MFMA O += V(t) P(t)  |  barrier
+// The K and V double buffers are therefore one tile out of phase.  exp2 does not overwrite the scores: P goes
+// straight to its packed bf16 form (the MFMA operand) and the row sum is taken over those rounded values with
+// v_dot2c_f32_bf16 (so the normaliser is the sum of exactly the weights P.V uses); the raw scores stay live until the
+// overflow check, whose rare redo (MODE 1 of the kernel above: true row maximum, rescale O / l, shift S(t) and the
+// already computed S(t+1)) therefore needs no second Q.K^T.
+template <int NW, int PRIO>
+__global__ __launch_bounds__(NW * 64, 2) void hk_attn_pipe_kernel(const AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * KT * 128];  // K stage 0, 1 | V stage 0, 1
+    constexpr int STG = KT * 128;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31;
+    const int h = lane >> 5;
+
+    const int nwg = gridDim.x;
+    int lid;
+    {
+        const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, rem = nwg & 7;
+        lid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (orig >> 3);
+    }
+    const int bh = lid / p.nqb;
+    const int qb = lid - bh * p.nqb;
+    const int b = bh / p.H;
+    const int head = bh - b * p.H;
+    const int q0 = qb * (NW * 32) + wave * 32;
+    const bool active = q0 < p.Nq;   // wave-uniform; an idle wave of the last query block still loads its K/V pieces
+
+    bf16x8 qf[4];
+    {
+        const int qrow = min(q0 + r, p.Nq - 1);
+        const __bf16* qp = p.Q + (int64_t)b * p.bsq + (int64_t)qrow * p.ldq + head * 64 + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+    }
+
+    // LDS-DMA addressing as in the kernel above (swizzle on the source chunk)
+    const int lkey = tid >> 3;
+    const int ck = (tid & 7) ^ ((lkey >> 1) & 7);
+    const int cv = (tid & 7) ^ (((lkey >> 1) & 1) << 2);
+    const char* kU = reinterpret_cast<const char*>(p.K + (int64_t)b * p.bsk + head * 64);
+    const char* vU = reinterpret_cast<const char*>(p.V + (int64_t)b * p.bsv + head * 64);
+    const uint32_t klane = (uint32_t)(((int64_t)lkey * p.ldk + ck * 8) * 2);
+    const uint32_t vlane = (uint32_t)(((int64_t)lkey * p.ldv + cv * 8) * 2);
+    const int64_t k32b = 64 * p.ldk, v32b = 64 * p.ldv;
+    auto kdma = [&](int tile, int stage) {
+        char* ks = smem + stage * STG + wave * 8 * 128;
+        if ((tile + 1) * KT <= p.Nk) {
+            const char* kt_ = kU + (int64_t)tile * 2 * k32b;
+            glds16_s(kt_, klane, ks);
+            if (NW == 4) glds16_s(kt_ + k32b, klane, ks + 32 * 128);
+        } else {
+#pragma unroll
+            for (int i = 0; i < (NW == 4 ? 2 : 1); ++i) {
+                const int key = min(tile * KT + i * 32 + lkey, p.Nk - 1);
+                glds16_v(p.K + (int64_t)b * p.bsk + head * 64 + ck * 8 + (int64_t)key * p.ldk, ks + i * 32 * 128);
+            }
+        }
+    };
+    auto vdma = [&](int tile, int stage) {
+        char* vs = smem + (2 + stage) * STG + wave * 8 * 128;
+        if ((tile + 1) * KT <= p.Nk) {
+            const char* vt_ = vU + (int64_t)tile * 2 * v32b;
+            glds16_s(vt_, vlane, vs);
+            if (NW == 4) glds16_s(vt_ + v32b, vlane, vs + 32 * 128);
+        } else {
+#pragma unroll
+            for (int i = 0; i < (NW == 4 ? 2 : 1); ++i) {
+                const int key = min(tile * KT + i * 32 + lkey, p.Nk - 1);
+                glds16_v(p.V + (int64_t)b * p.bsv + head * 64 + cv * 8 + (int64_t)key * p.ldv, vs + i * 32 * 128);
+            }
+        }
+    };
+
+    const int ksw = (r >> 1) & 7;
+    int koff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = r * 128 + (((2 * ks + h) ^ ksw) << 4);
+    const int vq = (lane & 15) >> 2;
+    const int vsb = (vq >> 1) & 1;
+    int voff[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        const int c = 4 * dt + 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);
+        voff[dt] = (4 * h + vq) * 128 + ((c ^ (vsb << 2)) << 4) + 8 * (lane & 1);
+    }
+
+    f32x16 ot[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ot[dt][i] = 0.f;
+    float m_run = 0.f, l_run = 0.f;
+    // -m_run in 16 registers: the initial accumulator (srcC) of every Q.K^T chain; rebuilt only when m_run moves.
+    // Built through asm so the compiler keeps the block instead of re-materialising it with 8 moves per tile.
+    f32x16 cneg;
+    auto set_cneg = [&]() {
+        typedef __attribute__((ext_vector_type(2))) float f32x2;
+        const f32x2 negm2 = {-m_run, -m_run};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            f32x2 c2;
+            asm volatile("v_mov_b64 %0, %1" : "=v"(c2) : "v"(negm2));
+            cneg[2 * j] = c2[0];
+            cneg[2 * j + 1] = c2[1];
+        }
+    };
+
+    const int NT = (p.Nk + KT - 1) / KT;
+    const bool ragged = (p.Nk % KT) != 0;
+#ifdef HK_ATTN_STAMP
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+#define HK_STAMP_BEGIN() tprev = __builtin_amdgcn_s_memtime()
+#define HK_STAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tprev; tprev = now_; } while (0)
+#else
+#define HK_STAMP_BEGIN() do {} while (0)
+#define HK_STAMP(i) do {} while (0)
+#endif
+
+    auto rowmax = [&](const f32x16 (&st)[2]) {
+        float mx = fmaxf(st[0][0], st[0][1]);
+#pragma unroll
+        for (int i = 2; i < 16; i += 2) mx = fmaxf(mx, fmaxf(st[0][i], st[0][i + 1]));
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) mx = fmaxf(mx, fmaxf(st[1][i], st[1][i + 1]));
+        return half_swap_max(mx);
+    };
+    auto mask_ragged = [&](f32x16 (&st)[2], const int t) {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = t * KT + 32 * kt + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (key >= p.Nk) st[kt][i] = NEG_BIG;
+            }
+    };
+
+    if (!active) {
+        // A wave of the last query block with no rows of its own: it still owns one eighth / quarter of every K/V tile.
+        // Same loads, waits and barriers as the computing waves below, nothing else.
+        kdma(0, 0);
+        vdma(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (NT > 1) kdma(1, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int t = 0; t < NT; ++t) {
+            if (t + 1 < NT) {
+                if (t + 2 < NT) kdma(t + 2, t & 1);
+                vdma(t + 1, (t & 1) ^ 1);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---- prologue: K(0), V(0) -> stage 0; S(0) with the true row maximum as m_run; K(1) on its way meanwhile ----
+    f32x16 sa[2], sb[2];
+    kdma(0, 0);
+    vdma(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (NT > 1) kdma(1, 1);
+    {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sa[kt][i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(smem + kt * 32 * 128 + koff[s]);
+                sa[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sa[kt], 0, 0, 0);
+            }
+        }
+        if (ragged && NT == 1) mask_ragged(sa, 0);
+        const float mx = rowmax(sa);
+        m_run = mx;
+        set_cneg();
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sa[kt][i] -= mx;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    const bf16x2 ones2 = __builtin_bit_cast(bf16x2, 0x3f803f80u);
+
+    // sc: S(t) (raw, relative to m_run); sn: receives S(t + 1).  PAR = t & 1.
+    auto iter = [&](const int t, f32x16 (&sc)[2], f32x16 (&sn)[2], auto has_next_c, auto next_ragged_c, auto par_c) {
+        constexpr bool HAS_NEXT = decltype(has_next_c)::value;
+        constexpr bool NEXT_RAGGED = decltype(next_ragged_c)::value;
+        constexpr int PAR = decltype(par_c)::value;
+        const char* ks = smem + (PAR ^ 1) * STG;        // K(t + 1)
+        bf16x8 kf[8];   // K fragment g: key half g & 1, k-step g >> 1; loaded two MFMAs ahead
+        HK_STAMP_BEGIN();
+        if (HAS_NEXT) {
+            kf[0] = *reinterpret_cast<const bf16x8*>(ks + koff[0]);
+            kf[1] = *reinterpret_cast<const bf16x8*>(ks + 32 * 128 + koff[0]);
+            if (t + 2 < NT) kdma(t + 2, PAR);
+            vdma(t + 1, PAR ^ 1);
+        }
+        HK_STAMP(0);
+        uint32_t pw[16];
+        float rs0, rs1;
+        auto exp_chunk = [&](const int g) {  // score registers 4g .. 4g+3 of the 32
+            const int kt = g >> 2, i0 = 4 * (g & 3);
+            const float e0 = __builtin_amdgcn_exp2f(sc[kt][i0]);
+            const float e1 = __builtin_amdgcn_exp2f(sc[kt][i0 + 1]);
+            const float e2 = __builtin_amdgcn_exp2f(sc[kt][i0 + 2]);
+            const float e3 = __builtin_amdgcn_exp2f(sc[kt][i0 + 3]);
+            pw[2 * g] = pack_bf16x2(e0, e1);
+            pw[2 * g + 1] = pack_bf16x2(e2, e3);
+            rs0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, pw[2 * g]), ones2, rs0, false);
+            rs1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, pw[2 * g + 1]), ones2, rs1, false);
+        };
+        rs0 = 0.f;
+        rs1 = 0.f;
+        if (HAS_NEXT) {
+            if (PRIO & 2) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                if (g + 2 < 8) kf[g + 2] = *reinterpret_cast<const bf16x8*>(ks + ((g + 2) & 1) * 32 * 128 + koff[(g + 2) >> 1]);
+                sn[g & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[g], qf[g >> 1], g < 2 ? cneg : sn[g & 1], 0, 0, 0);
+                exp_chunk(g);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (PRIO & 2) __builtin_amdgcn_s_setprio(0);
+            if (NEXT_RAGGED) mask_ragged(sn, t + 1);
+        } else {
+#pragma unroll
+            for (int g = 0; g < 8; ++g) exp_chunk(g);
+        }
+        // V^T fragments by inline asm: the compiler orders a builtin LDS read after every LDS-DMA in flight (s_waitcnt
+        // vmcnt(0) in front of the first read, i.e. the K(t+2) / V(t+1) loads just issued would have to land before P.V
+        // starts).  These reads touch stage PAR only, the loads in flight write the other stage.  Fragment (s, dt) =
+        // two 8-byte transposed reads; the waits below are counted by hand (LDS returns in order) and carry the
+        // fragment registers as operands so no MFMA can move above its wait.
+        u32x2 vr[4][2][2];
+#define HK_VREAD(S, DT, U)                                                                                   \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2"                                                   \
+                     : "=v"(vr[S][DT][U])                                                                    \
+                     : "v"(voff[DT]), "n"((2 + PAR) * STG + (S) * 16 * 128 + (U) * 8 * 128))
+#define HK_VREAD4(S) HK_VREAD(S, 0, 0); HK_VREAD(S, 0, 1); HK_VREAD(S, 1, 0); HK_VREAD(S, 1, 1)
+#define HK_VWAIT(N, S)                                                                                       \
+        asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                             \
+                     : "+v"(vr[S][0][0]), "+v"(vr[S][0][1]), "+v"(vr[S][1][0]), "+v"(vr[S][1][1]))
+        HK_STAMP(1);
+        HK_VREAD4(0);
+        HK_VREAD4(1);
+        float rs = rs0 + rs1;
+        if (__builtin_amdgcn_ballot_w64(!(rs <= OVERFLOW_SUM)) != 0) {
+            const float delta = fmaxf(rowmax(sc), 0.f);
+            const float alpha = __builtin_amdgcn_exp2f(-delta);
+            m_run += delta;
+            set_cneg();
+            l_run *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) ot[dt][i] *= alpha;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    sc[kt][i] -= delta;
+                    if (HAS_NEXT) sn[kt][i] -= delta;
+                }
+            rs0 = 0.f;
+            rs1 = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) exp_chunk(g);
+            rs = rs0 + rs1;
+        }
+        l_run += rs;
+
+        if (PRIO & 1) __builtin_amdgcn_s_setprio(2);
+        auto pv = [&](const int s_) {
+            u32x4 w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = pw[4 * s_ + j];
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, w);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                u32x4 v4;
+                v4[0] = vr[s_][dt][0][0];
+                v4[1] = vr[s_][dt][0][1];
+                v4[2] = vr[s_][dt][1][0];
+                v4[3] = vr[s_][dt][1][1];
+                ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v4), pf, ot[dt], 0, 0, 0);
+            }
+        };
+        HK_VWAIT(4, 0);
+        pv(0);
+        __builtin_amdgcn_sched_barrier(0);
+        HK_VREAD4(2);
+        HK_VWAIT(4, 1);
+        pv(1);
+        __builtin_amdgcn_sched_barrier(0);
+        HK_VREAD4(3);
+        HK_VWAIT(4, 2);
+        pv(2);
+        __builtin_amdgcn_sched_barrier(0);
+        HK_VWAIT(0, 3);
+        pv(3);
+        __builtin_amdgcn_sched_barrier(0);
+#undef HK_VREAD
+#undef HK_VREAD4
+#undef HK_VWAIT
+        if (PRIO & 1) __builtin_amdgcn_s_setprio(0);
+        HK_STAMP(2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        HK_STAMP(3);
+        __syncthreads();
+        HK_STAMP(4);
+    };
+
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    auto run = [&](const int t, auto has_next_c, auto next_ragged_c) {
+        if (t & 1) iter(t, sb, sa, has_next_c, next_ragged_c, S1{});
+        else iter(t, sa, sb, has_next_c, next_ragged_c, S0{});
+    };
+    const int NS = ragged ? NT - 2 : NT - 1;   // iterations [0, NS) produce a whole next tile
+    int t = 0;
+    for (; t + 1 < NS; t += 2) {
+        iter(t, sa, sb, T_{}, F_{}, S0{});
+        iter(t + 1, sb, sa, T_{}, F_{}, S1{});
+    }
+    if (t < NS) {
+        run(t, T_{}, F_{});
+        ++t;
+    }
+    if (ragged && NT >= 2) run(NT - 2, T_{}, T_{});
+    run(NT - 1, F_{}, F_{});
+
+#ifdef HK_ATTN_STAMP
+    if (p.stamp && lane == 0) {
+        unsigned long long* o = p.stamp + ((size_t)blockIdx.x * NW + wave) * 8;
+        for (int i = 0; i < 5; ++i) o[i] = tacc[i];
+        o[5] = (unsigned long long)NT;
+    }
+#endif
+#undef HK_STAMP
+#undef HK_STAMP_BEGIN
+    // ---- normalise and store (as above) ----
+    const float l_tot = half_swap_sum(l_run);
+    const float inv = 1.0f / l_tot;
+    if (p.o_vec16) {
+        char* stg = smem + wave * 4096;
+        const int sw = (r >> 1) & 7;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 o;
+                o[0] = pack_bf16x2(ot[dt][4 * g] * inv, ot[dt][4 * g + 1] * inv);
+                o[1] = pack_bf16x2(ot[dt][4 * g + 2] * inv, ot[dt][4 * g + 3] * inv);
+                *reinterpret_cast<u32x2*>(stg + r * 128 + (((4 * dt + g) ^ sw) << 4) + 8 * h) = o;
+            }
+        __bf16* ob = p.O + (int64_t)b * p.bso + head * 64 + (lane & 7) * 8;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 8 + (lane >> 3);
+            const u32x4 o = *reinterpret_cast<const u32x4*>(stg + row * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4));
+            if (q0 + row < p.Nq) *reinterpret_cast<u32x4*>(ob + (int64_t)(q0 + row) * p.ldo) = o;
+        }
+        return;
+    }
+    const int qrow = q0 + r;
+    if (qrow < p.Nq) {
+        __bf16* op = p.O + (int64_t)b * p.bso + (int64_t)qrow * p.ldo + head * 64 + 4 * h;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 o;
+                o[0] = pack_bf16x2(ot[dt][4 * g] * inv, ot[dt][4 * g + 1] * inv);
+                o[1] = pack_bf16x2(ot[dt][4 * g + 2] * inv, ot[dt][4 * g + 3] * inv);
+                *reinterpret_cast<u32x2*>(op + 32 * dt + 8 * g) = o;
+            }
+    }
+}
+
 }  // namespace
 
 int hk_attn_causal_dispatch(const hk_attn_desc* d, void* stream);  // hk_attn_causal.hip
@@ -481,6 +930,10 @@ extern "C" int hk_flash_attn_bf16(const hk_attn_desc* d, void* stream) {
     p.nqb = (d->Nq + QB - 1) / QB;
     static const int prio = getenv("HK_ATTN_PRIO") ? atoi(getenv("HK_ATTN_PRIO")) : 1;
     p.prio = prio;
+    p.stamp = nullptr;
+#ifdef HK_ATTN_STAMP
+    if (getenv("HK_ATTN_STAMP_PTR")) p.stamp = reinterpret_cast<unsigned long long*>(strtoull(getenv("HK_ATTN_STAMP_PTR"), nullptr, 0));
+#endif
     // HK_ATTN_EPI=0: A/B aid, per-lane 8-byte stores everywhere
     static const int epi = getenv("HK_ATTN_EPI") ? atoi(getenv("HK_ATTN_EPI")) : 1;
     p.o_vec16 = (epi != 0 && d->ldo % 8 == 0 && d->bso % 8 == 0) ? 1 : 0;
@@ -496,8 +949,23 @@ extern "C" int hk_flash_attn_bf16(const hk_attn_desc* d, void* stream) {
 #define HK_ATTN_LAUNCH(BIAS, M, O, L) hipLaunchKernelGGL((hk_attn_kernel<BIAS, M, O, L>), grid, block, 0, s, p)
     // key-bias (Q-Former text mask) launches: the tuned loader / softmax form too; HK_ATTN_BIAS=0: the first-round variant
     static const int bvar = getenv("HK_ATTN_BIAS") ? atoi(getenv("HK_ATTN_BIAS")) : 1;
-    if (d->key_bias && bvar == 0) HK_ATTN_LAUNCH(true, 0, 1, 0);
+    // HK_ATTN_PIPE: 2 / 8 = the software-pipelined kernel with 4 / 8 waves per workgroup (no key bias); 0 (default) = the
+    // per-tile kernel.  Measured on one device, B=32 N=3136: per-tile 1356 us, pipelined 1457 (4 waves) / 1505 (8 waves):
+    // the loop is bound by vector issue slots per tile, not by latency, so overlapping a wave's own phases buys nothing.
+    static const int pipe = getenv("HK_ATTN_PIPE") ? atoi(getenv("HK_ATTN_PIPE")) : 0;
+    if (!d->key_bias && (pipe == 2 || pipe == 8)) {
+        const int nw = pipe == 8 ? 8 : 4;
+        p.nqb = (d->Nq + nw * 32 - 1) / (nw * 32);
+        const dim3 g2((unsigned)((long)p.nqb * d->H * d->B)), b2(nw * 64);
+        if (nw == 4 && prio == 0) hipLaunchKernelGGL((hk_attn_pipe_kernel<4, 0>), g2, b2, 0, s, p);
+        else if (nw == 4) hipLaunchKernelGGL((hk_attn_pipe_kernel<4, 1>), g2, b2, 0, s, p);
+        else if (prio == 0) hipLaunchKernelGGL((hk_attn_pipe_kernel<8, 0>), g2, b2, 0, s, p);
+        else hipLaunchKernelGGL((hk_attn_pipe_kernel<8, 1>), g2, b2, 0, s, p);
+    }
+    else if (d->key_bias && bvar == 0) HK_ATTN_LAUNCH(true, 0, 1, 0);
     else if (d->key_bias) HK_ATTN_LAUNCH(true, 1, 2, 1);
+    else if (ldr == 2 && mode == 1 && occ == 3) HK_ATTN_LAUNCH(false, 1, 3, 2);
+    else if (ldr == 2 && mode == 1) HK_ATTN_LAUNCH(false, 1, 2, 2);
     else if (ldr == 1 && mode == 1 && occ == 3) HK_ATTN_LAUNCH(false, 1, 3, 1);
     else if (ldr == 1 && mode == 1) HK_ATTN_LAUNCH(false, 1, 2, 1);
     else if (ldr == 1 && occ == 3) HK_ATTN_LAUNCH(false, 0, 3, 1);
