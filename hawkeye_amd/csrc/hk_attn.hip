@@ -42,6 +42,8 @@ constexpr int QB = 128;   // query rows per workgroup
 constexpr int KT = 64;    // keys per tile
 constexpr float NEG_BIG = -1.0e30f;
 constexpr float OVERFLOW_SUM = 1048576.0f;  // 2^20: a lane's 32-score partial row sum beyond this redoes the tile
+constexpr float NOMAX_SUM = 1.2676506e30f;        // 2^100: MODE 2's no-maximum pass gives up beyond this partial row sum ...
+constexpr float NOMAX_MIN_TOTAL = 7.8886091e-31f;  // ... or below this (2^-100) row total
 
 // v_permlane32_swap exchanges lanes 32-63 of its first operand with lanes 0-31 of its second:
 // called on two copies of x, one result holds (own, partner) and the other (partner, own).
@@ -239,14 +241,7 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
     if (LOADER == 2) set_cneg();
 
     const int NT = (p.Nk + KT - 1) / KT;
-    if (LOADER >= 1) {
-        gdma(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-        gload(0);
-        lstore(0);
-    }
-    __syncthreads();
+    bool bad = false;   // MODE 2, first pass: some score left the range the no-maximum form covers
 
     // One K/V tile.  FIRST (tile 0) and RAGGED (last tile when Nk % 64 != 0) are compile-time so the
     // steady-state body carries neither the key mask nor the first-tile special case.
@@ -258,13 +253,20 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
     //   first tile and afterwards only when a tile "overflows" -- some lane's partial row sum leaves
     //   [0, OVERFLOW_SUM], i.e. a score exceeded m_run by ~20 bits or exp2 returned inf; that tile is
     //   redone with the maximum taken.
+    // MODE 2: first a pass with NO running maximum at all -- P = exp2(s) as it comes out of the MFMA (initial
+    //   accumulator = the inline constant 0: no -m block to build per tile, no first-tile maximum).  bf16 has fp32's
+    //   exponent range, so P, l and O keep full relative precision for any |s| < ~100 (log2 units; a trained ViT's
+    //   scaled logits stay within a few tens); the pass only records whether a partial row sum left [0, 2^100] or a
+    //   row's total fell below 2^-100.  If any wave of the workgroup recorded that, the whole workgroup runs the
+    //   MODE 1 pass from the start -- the result is then that pass's, bit for bit.
     // Either way the decision is wave-uniform, is taken after the previous tile's P.V is complete and
     // before any P of this tile is used, so O, l and this tile's scores are the only things at the
     // old scale when a rescale happens.
     // The LDS stage (t & 1) is a compile-time argument too -- the steady-state loop is unrolled by two -- so every
     // fragment address is base register + immediate offset.
-    auto tile = [&](const int t, auto first_c, auto ragged_c, auto cur_c) {
-        constexpr bool FIRST = decltype(first_c)::value;
+    auto tile = [&](const int t, auto first_c, auto ragged_c, auto cur_c, auto mode_c) {
+        constexpr int M = decltype(mode_c)::value;   // 0, 1 as above; 3 = the no-maximum pass of MODE 2
+        constexpr bool FIRST = decltype(first_c)::value && M != 3;
         constexpr bool RAGGED = decltype(ragged_c)::value;
         constexpr int cur = decltype(cur_c)::value;
         if (t + 1 < NT) {
@@ -282,7 +284,10 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
             typedef __attribute__((ext_vector_type(2))) float f32x2;
             const f32x2 negm2 = {-m_run, -m_run};
             f32x16 cinit;
-            if (LOADER == 2) {
+            if (M == 3) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) cinit[j] = 0.f;   // folds into the MFMA's inline-constant srcC
+            } else if (LOADER == 2) {
                 cinit = cneg;
             } else {
 #pragma unroll
@@ -368,10 +373,13 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
         };
 
         scores();
-        if (FIRST) {
+        if (M == 3) {
+            exp_sum();
+            bad |= __builtin_amdgcn_ballot_w64(!(rs <= NOMAX_SUM)) != 0;
+        } else if (FIRST) {
             move_max(rowmax());
             exp_sum();
-        } else if (MODE == 0) {
+        } else if (M == 0) {
             const float mx = rowmax();
             if (__builtin_amdgcn_ballot_w64(mx > 8.0f) != 0) move_max(mx);
             exp_sum();
@@ -434,28 +442,60 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
     const bool ragged = (p.Nk % KT) != 0;
-    auto last = [&](const int t, auto first_c) {
-        if (t & 1) {
-            if (ragged) tile(t, first_c, T_{}, S1{}); else tile(t, first_c, F_{}, S1{});
+    auto run_pass = [&](auto mode_c) {
+        if (LOADER >= 1) {
+            gdma(0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
-            if (ragged) tile(t, first_c, T_{}, S0{}); else tile(t, first_c, F_{}, S0{});
+            gload(0);
+            lstore(0);
+        }
+        __syncthreads();
+        auto last = [&](const int t, auto first_c) {
+            if (t & 1) {
+                if (ragged) tile(t, first_c, T_{}, S1{}, mode_c); else tile(t, first_c, F_{}, S1{}, mode_c);
+            } else {
+                if (ragged) tile(t, first_c, T_{}, S0{}, mode_c); else tile(t, first_c, F_{}, S0{}, mode_c);
+            }
+        };
+        if (NT == 1) {
+            last(0, T_{});
+        } else {
+            tile(0, T_{}, F_{}, S0{}, mode_c);
+            int t = 1;
+            for (; t + 1 < NT - 1; t += 2) {
+                tile(t, F_{}, F_{}, S1{}, mode_c);
+                tile(t + 1, F_{}, F_{}, S0{}, mode_c);
+            }
+            if (t < NT - 1) tile(t, F_{}, F_{}, S1{}, mode_c);
+            last(NT - 1, F_{});
         }
     };
-    if (NT == 1) {
-        last(0, T_{});
-    } else {
-        tile(0, T_{}, F_{}, S0{});
-        int t = 1;
-        for (; t + 1 < NT - 1; t += 2) {
-            tile(t, F_{}, F_{}, S1{});
-            tile(t + 1, F_{}, F_{}, S0{});
+    float l_tot;
+    if (MODE == 2) {
+        run_pass(std::integral_constant<int, 3>{});
+        l_tot = half_swap_sum(l_run);
+        bad |= __builtin_amdgcn_ballot_w64(!(l_tot >= NOMAX_MIN_TOTAL)) != 0;
+        if (__syncthreads_or(bad ? 1 : 0)) {   // uniform over the workgroup (its waves share every barrier of a pass)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) ot[dt][i] = 0.f;
+            m_run = 0.f;
+            l_run = 0.f;
+            if (LOADER == 0) {
+                kp = kbase + (int64_t)lkey * p.ldk;
+                vp_ = vbase + (int64_t)lkey * p.ldv;
+            }
+            run_pass(std::integral_constant<int, 1>{});
+            l_tot = half_swap_sum(l_run);
         }
-        if (t < NT - 1) tile(t, F_{}, F_{}, S1{});
-        last(NT - 1, F_{});
+    } else {
+        run_pass(std::integral_constant<int, MODE>{});
+        l_tot = half_swap_sum(l_run);
     }
 
     // ---- normalise and store: lane (r, h) holds O[q0 + r][32 dt + 8 g + 4 h .. +4] ----
-    const float l_tot = half_swap_sum(l_run);
     const float inv = 1.0f / l_tot;
     if (p.o_vec16) {
         // Whole 128-byte row segments: the wave's 32 x 64 bf16 block is transposed through its own 4 KB of the
@@ -964,6 +1004,8 @@ extern "C" int hk_flash_attn_bf16(const hk_attn_desc* d, void* stream) {
     }
     else if (d->key_bias && bvar == 0) HK_ATTN_LAUNCH(true, 0, 1, 0);
     else if (d->key_bias) HK_ATTN_LAUNCH(true, 1, 2, 1);
+    else if (mode == 2 && occ == 3) HK_ATTN_LAUNCH(false, 2, 3, 1);
+    else if (mode == 2) HK_ATTN_LAUNCH(false, 2, 2, 1);
     else if (ldr == 2 && mode == 1 && occ == 3) HK_ATTN_LAUNCH(false, 1, 3, 2);
     else if (ldr == 2 && mode == 1) HK_ATTN_LAUNCH(false, 1, 2, 2);
     else if (ldr == 1 && mode == 1 && occ == 3) HK_ATTN_LAUNCH(false, 1, 3, 1);

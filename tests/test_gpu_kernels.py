@@ -247,6 +247,37 @@ def test_flash_attention_rescale_branch_with_spiked_keys():
     assert (o.float() - ref).abs().max().item() < 3e-2
 
 
+def test_flash_attention_all_scores_far_below_zero():
+    """Every score of a row near -300 (log2 units): exp2 of the raw scores underflows, so the no-maximum first pass of the
+    default kernel must notice the vanishing row totals and hand over to the running-maximum pass."""
+    B, H, Nq, Nk = 1, 2, 160, 200
+    u = _rand((1, 1, H, 64), 41, 0.5, torch.bfloat16)
+    q = (u + _rand((B, Nq, H, 64), 42, 0.02, torch.bfloat16)).to(torch.bfloat16)
+    k = (-20.0 * u + _rand((B, Nk, H, 64), 43, 0.5, torch.bfloat16)).to(torch.bfloat16)
+    v = _rand((B, Nk, H, 64), 44, 1.0, torch.bfloat16)
+    o = ops.flash_attention(q, k, v)
+    ref = _attn_ref(q, k, v)
+    assert torch.isfinite(o.float()).all()
+    assert (o.float() - ref).abs().max().item() < 3e-2
+
+
+@pytest.mark.parametrize("env", [{"HK_ATTN_PIPE": "2"}, {"HK_ATTN_PIPE": "8"}, {"HK_ATTN_MODE": "2"}, {"HK_ATTN_LOADER": "2"}])
+def test_flash_attention_measured_variants_stay_correct(env):
+    """The attention variants kept for A/B (software-pipelined kernel with 4 / 8 waves, no-maximum first pass, resident
+    -m block) are selected by environment variables the library reads once per process: run this file's attention
+    tests in a child process per variant."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("HK_ATTN_VARIANT_CHILD"):
+        pytest.skip("already inside a variant run")
+    child_env = dict(os.environ, HK_ATTN_VARIANT_CHILD="1", **env)
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-x", "-q", "-k", "flash_attention and not variants",
+                        "--timeout", "120", "--timeout-method", "thread", "-p", "no:cacheprovider"],
+                       env=child_env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("D,eps,in_bf16", [(1024, 1e-6, False), (768, 1e-12, False), (128, 1e-12, True), (256, 1e-6, False)])
 def test_layernorm(D, eps, in_bf16):
     rows = 1003
