@@ -66,25 +66,6 @@ __device__ __forceinline__ float half_swap_sum(float x) {
     return a + b;
 }
 
-// LDS-DMA with a scalar base: address = SGPR pair + one 32-bit per-lane byte offset (no 64-bit vector address
-// arithmetic per piece).  Inline asm: the builtin always takes a 64-bit vector address.  lds = the wave's destination.
-__device__ __forceinline__ void glds16_s(const void* sbase, uint32_t voff, const void* lds) {
-    const uint32_t la = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                 :
-                 : "v"(voff), "s"(sbase), "s"(la)
-                 : "memory");
-}
-// The same with a 64-bit per-lane address (ragged last tile).  The pipelined kernel issues every LDS-DMA through these two
-// helpers, so the compiler itself never holds a value in M0 there (M0 is reserved and cannot be named as a clobber).
-__device__ __forceinline__ void glds16_v(const void* vaddr, const void* lds) {
-    const uint32_t la = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                 :
-                 : "v"(vaddr), "s"(la)
-                 : "memory");
-}
-
 template <bool HAS_BIAS, int MODE, int OCC, int LOADER>
 __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KT * 128];  // [stage][K|V][64 keys][128 B]

@@ -31,6 +31,35 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// LDS-DMA with a scalar base: address = SGPR pair + one 32-bit per-lane byte offset (no 64-bit vector address
+// arithmetic per piece).  Inline asm: the builtin always takes a 64-bit vector address.  lds = the wave's destination.
+__device__ __forceinline__ void glds16_s(const void* sbase, uint32_t voff, const void* lds) {
+    const uint32_t la = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :
+                 : "v"(voff), "s"(sbase), "s"(la)
+                 : "memory");
+}
+// The same with a 64-bit per-lane address.  A kernel that uses these helpers issues EVERY LDS-DMA through them, so the
+// compiler itself never holds a value in M0 there (M0 is reserved and cannot be named as a clobber), and retires them with
+// its own counted s_waitcnt vmcnt (the compiler does not know these statements write LDS).
+__device__ __forceinline__ void glds16_v(const void* vaddr, const void* lds) {
+    const uint32_t la = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :
+                 : "v"(vaddr), "s"(la)
+                 : "memory");
+}
+
+// 4 bytes per lane (256 B per wave-instruction), scalar base + 32-bit lane offset.
+__device__ __forceinline__ void glds4_s(const void* sbase, uint32_t voff, const void* lds) {
+    const uint32_t la = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1"
+                 :
+                 : "v"(voff), "s"(sbase), "s"(la)
+                 : "memory");
+}
+
 void hk_set_error(const char* fmt, ...);
 
 #define HK_REQUIRE(cond, ...)            \

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
     // ---- loader: one LDS-DMA wave-instruction = 8 rows x 128 B; a half-tile = 2 per thread.
     // Each slot kind (A-h0, A-h1, W-h0, W-h1) has its own cursor into the K-tile stream. ----
     const int lrow = lane >> 3, lpc = lane & 7;
-    const __bf16* gp[4][2];  // [slot kind][round]: row base of the tile being staged
+    uint32_t go[4][2];  // [slot kind][round]: byte offset (from A / W) of the row piece of the tile being staged
     int s_tile[4], s_k[4], s_par[4];
     auto set_ptrs = [&](int kind) {
         const int lid = c0 + jb + s_tile[kind] * nbx;
@@ -246,18 +246,20 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
             const int sw = (lpc ^ ((row >> 1) & 7)) << 3;
             if (kind < 2) {
                 const int m = min(t0 + kind * 128 + row, p.M - 1);
-                gp[kind][i] = p.A + p.a.off(m) + sw;
+                go[kind][i] = (uint32_t)((p.a.off(m) + sw) * 2);
             } else {
                 const int n = min(t0 + (kind - 2) * 128 + row, p.N - 1);
-                gp[kind][i] = p.W + (int64_t)n * p.ldw + sw;
+                go[kind][i] = (uint32_t)(((int64_t)n * p.ldw + sw) * 2);
             }
         }
     };
     auto stage = [&](int kind) -> bool {  // stage the cursor's half-tile, advance the cursor
         if (s_tile[kind] >= ntile) return false;
         __bf16* dst = lds + s_par[kind] * BUF + kind * HALF + wave * 8 * BK;
-        glds16(gp[kind][0] + s_k[kind] * BK, dst);
-        glds16(gp[kind][1] + s_k[kind] * BK, dst + 64 * BK);
+        // scalar base (operand + K offset) + the piece's 32-bit lane offset: no 64-bit vector address per piece
+        const __bf16* kb = (kind < 2 ? p.A : p.W) + s_k[kind] * BK;
+        glds16_s(kb, go[kind][0], dst);
+        glds16_s(kb, go[kind][1], dst + 64 * BK);
         s_par[kind] ^= 1;
         if (++s_k[kind] == KT) {
             s_k[kind] = 0;
@@ -343,15 +345,17 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
                         for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[a][b][i][j]));
             return;
         }
+        // bias of the wave's 64 columns: staged into the slab (bytes 1024..1279) by one 4-byte LDS-DMA at the start of
+        // the tile (main loop below) -- a global load here would be the youngest vector-memory operation of the wave, and
+        // waiting for it would also wait for every operand load of the next tile already in flight.
         f32x4 bias[2][2];
 #pragma unroll
         for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int n = n0 + wn * 64 + nh * 32 + j * 16 + (lane >> 4) * 4;
-                bias[nh][j] = (p.bias != nullptr && n < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + n)
-                                                             : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            for (int j = 0; j < 2; ++j)
+                bias[nh][j] = p.bias != nullptr
+                                  ? *reinterpret_cast<const f32x4*>(stg + 1024 + (nh * 32 + j * 16 + (lane >> 4) * 4) * 4)
+                                  : f32x4{0.f, 0.f, 0.f, 0.f};
         constexpr bool FOLD = EPI == 3;
         float rs[2][4], rm[2][4];
         f32x4 cc[2][2];
@@ -559,13 +563,19 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
     }
     int buf = 0;
     for (int ti = 0; ti < ntile; ++ti) {
+        if (p.bias != nullptr) {
+            // this tile's bias slice -> the wave's staging slab (idle until the epilogue); columns past N are never stored
+            int tm_, tn_;
+            tile_coords(c0 + jb + ti * nbx, p.nbm, p.nbn, p.gm, tm_, tn_);
+            glds4_s(p.bias, (uint32_t)min(tn_ * 256 + wn * 64 + lane, p.N - 1) * 4u, stg + 1024);
+        }
         if (EPI == 3) {
             // folded LayerNorm: (mean, rstd) of the wave's 128 rows -> its staging slab (idle until the epilogue),
             // 2 rows per lane.  Issued outside the K loop, whose body stays that of EPI 0; older than every operand
             // load of this tile, so the first counted vmcnt retires it.
             int tm_, tn_;
             tile_coords(c0 + jb + ti * nbx, p.nbm, p.nbn, p.gm, tm_, tn_);
-            glds16(p.row_stats + 2 * ((int64_t)tm_ * 256 + wm * 128 + 2 * lane), stg);
+            glds16_v(p.row_stats + 2 * ((int64_t)tm_ * 256 + wm * 128 + 2 * lane), stg);
         }
         for (int t = 0; t < KT; ++t) {
             // phase 1
@@ -894,7 +904,13 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
     // from half a chip's worth of 256x256 tiles up (one tile per CU, the rest idle) the ping-pong kernel still beats
     // the multi-stage one: measured crossover ~128 tiles (prefill o_proj / down_proj at M = 2816: 42.1 -> 39.3 ms)
     static const int pp_min = getenv("HK_GEMM_PP_MIN") ? atoi(getenv("HK_GEMM_PP_MIN")) : 128;
-    if (variant != 0 && tiles256 >= pp_min && d->N % 256 == 0) {
+    // the persistent kernel addresses its operand pieces as scalar base + 32-bit byte offset
+    const int64_t a_last = d->a_rows.rows_per_batch == 0
+                               ? (int64_t)(d->M - 1) * d->a_rows.ld
+                               : (int64_t)((d->M - 1) / d->a_rows.rows_per_batch) * d->a_rows.batch_stride +
+                                     (int64_t)((d->M - 1) % d->a_rows.rows_per_batch) * d->a_rows.ld;
+    const bool off32 = (a_last + d->K) * 2 < (1LL << 32) && (int64_t)d->N * d->ldw * 2 < (1LL << 32);
+    if (variant != 0 && tiles256 >= pp_min && d->N % 256 == 0 && off32) {
         // Tail balance: the persistent kernel gives each of the 256 CUs floor or ceil(tiles / 256) tiles, so a
         // last round that is less than half full (e.g. 1568 tiles = 6.125 rounds) idles most of the chip for a
         // whole tile time.  Then the rows of that partial round go to the multi-stage kernel as a second
