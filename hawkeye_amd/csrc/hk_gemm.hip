@@ -373,10 +373,8 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
 #pragma unroll
             for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int n = n0 + wn * 64 + nh * 32 + j * 16 + (lane >> 4) * 4;
-                    cc[nh][j] = n < p.N ? *reinterpret_cast<const f32x4*>(p.col_c + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-                }
+                for (int j = 0; j < 2; ++j)   // column sums of W: staged like the bias, slab bytes 1280..1535
+                    cc[nh][j] = *reinterpret_cast<const f32x4*>(stg + 1280 + (nh * 32 + j * 16 + (lane >> 4) * 4) * 4);
         }
         auto pre = [&](f32x4 v, int nh, int j, int mh, int i) {
             const int n = n0 + wn * 64 + nh * 32 + j * 16 + (lane >> 4) * 4;
@@ -440,6 +438,8 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
 #pragma unroll
                     for (int it = 0; it < 2; ++it) {
                         const int m = mw + rnd * 16 + it * 8 + (lane >> 3), n = nw + (lane & 7) * 8;
+                        // (kept inside the bounds branch: with unconditional, row-clamped loads the compiler counts its
+                        // waits -- vmcnt(3) / (2) instead of (0) -- and proj / fc2 measured 1.7 % SLOWER in situ)
                         rr[it] = (m < p.M && n < p.N)
                                      ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const __bf16*>(p.res) + p.r.off(m) + n)
                                      : u32x4{0u, 0u, 0u, 0u};
@@ -568,6 +568,7 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
             int tm_, tn_;
             tile_coords(c0 + jb + ti * nbx, p.nbm, p.nbn, p.gm, tm_, tn_);
             glds4_s(p.bias, (uint32_t)min(tn_ * 256 + wn * 64 + lane, p.N - 1) * 4u, stg + 1024);
+            if (EPI == 3) glds4_s(p.col_c, (uint32_t)min(tn_ * 256 + wn * 64 + lane, p.N - 1) * 4u, stg + 1280);
         }
         if (EPI == 3) {
             // folded LayerNorm: (mean, rstd) of the wave's 128 rows -> its staging slab (idle until the epilogue),
