@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
     const __bf16* kp = kbase + (int64_t)lkey * p.ldk;   // this thread's rows of the NEXT tile to load
     const __bf16* vp_ = vbase + (int64_t)lkey * p.ldv;
     const int64_t k32 = 32 * p.ldk, v32 = 32 * p.ldv;
-    auto gload = [&](int tile) {
+    auto gload = [&](int tile) __attribute__((always_inline)) {
         if ((tile + 1) * KT <= p.Nk) {
             kr[0] = *reinterpret_cast<const bf16x8*>(kp);
             kr[1] = *reinterpret_cast<const bf16x8*>(kp + k32);
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
         kp += 2 * k32;
         vp_ += 2 * v32;
     };
-    auto lstore = [&](int stage) {
+    auto lstore = [&](int stage) __attribute__((always_inline)) {
         char* ks = smem + stage * (2 * KT * 128);
         char* vs = ks + KT * 128;
 #pragma unroll
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
     const uint32_t klane = (uint32_t)(((int64_t)lkey * p.ldk + ck * 8) * 2);
     const uint32_t vlane = (uint32_t)(((int64_t)lkey * p.ldv + cv * 8) * 2);
     const int64_t k32b = 64 * p.ldk, v32b = 64 * p.ldv;  // 32 key rows, in bytes
-    auto gdma = [&](int tile, int stage) {
+    auto gdma = [&](int tile, int stage) __attribute__((always_inline)) {
         char* ks = smem + stage * (2 * KT * 128) + wave * 8 * 128;
         char* vs = ks + KT * 128;
         if ((tile + 1) * KT <= p.Nk) {
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
     float m_run = 0.f, l_run = 0.f;  // every stored quantity is relative to m_run
     // LOADER 2: -m_run kept in 16 registers as the srcC of the first MFMA of each chain, rebuilt only when m_run moves
     f32x16 cneg;
-    auto set_cneg = [&]() {
+    auto set_cneg = [&]() __attribute__((always_inline)) {
         typedef __attribute__((ext_vector_type(2))) float f32x2;
         const f32x2 negm2 = {-m_run, -m_run};
 #pragma unroll
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
     // old scale when a rescale happens.
     // The LDS stage (t & 1) is a compile-time argument too -- the steady-state loop is unrolled by two -- so every
     // fragment address is base register + immediate offset.
-    auto tile = [&](const int t, auto first_c, auto ragged_c, auto cur_c, auto mode_c) {
+    auto tile = [&](const int t, auto first_c, auto ragged_c, auto cur_c, auto mode_c) __attribute__((always_inline)) {
         constexpr int M = decltype(mode_c)::value;   // 0, 1 as above; 3 = the no-maximum pass of MODE 2
         constexpr bool FIRST = decltype(first_c)::value && M != 3;
         constexpr bool RAGGED = decltype(ragged_c)::value;
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
         f32x16 st[2];
         float rs;
 
-        auto scores = [&]() {
+        auto scores = [&]() __attribute__((always_inline)) {
             if (p.prio) __builtin_amdgcn_s_setprio(1);
             // initial accumulator = -m_run in all 16 registers, built with 8 v_mov_b64 (one block serves both key
             // halves).  Keeping the block alive across tiles instead measured 1.5 % slower (register pressure).
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
                     }
             }
         };
-        auto rowmax = [&]() {
+        auto rowmax = [&]() __attribute__((always_inline)) {
             float mx = fmaxf(st[0][0], st[0][1]);
 #pragma unroll
             for (int i = 2; i < 16; i += 2) mx = fmaxf(mx, fmaxf(st[0][i], st[0][i + 1]));
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
             for (int i = 0; i < 16; i += 2) mx = fmaxf(mx, fmaxf(st[1][i], st[1][i + 1]));
             return half_swap_max(mx);
         };
-        auto move_max = [&](const float mx) {  // m_run += delta; everything at the old scale follows
+        auto move_max = [&](const float mx) __attribute__((always_inline)) {  // m_run += delta; everything at the old scale follows
             const float delta = FIRST ? mx : fmaxf(mx, 0.f);
             const float alpha = FIRST ? 0.f : __builtin_amdgcn_exp2f(-delta);
             m_run += delta;
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) st[kt][i] -= delta;
         };
-        auto exp_sum = [&]() {
+        auto exp_sum = [&]() __attribute__((always_inline)) {
             rs = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
     const bool ragged = (p.Nk % KT) != 0;
-    auto run_pass = [&](auto mode_c) {
+    auto run_pass = [&](auto mode_c) __attribute__((always_inline)) {
         if (LOADER >= 1) {
             gdma(0, 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
             lstore(0);
         }
         __syncthreads();
-        auto last = [&](const int t, auto first_c) {
+        auto last = [&](const int t, auto first_c) __attribute__((always_inline)) {
             if (t & 1) {
                 if (ragged) tile(t, first_c, T_{}, S1{}, mode_c); else tile(t, first_c, F_{}, S1{}, mode_c);
             } else {
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(NW * 64, 2) void hk_attn_pipe_kernel(const AttnPara
     const uint32_t klane = (uint32_t)(((int64_t)lkey * p.ldk + ck * 8) * 2);
     const uint32_t vlane = (uint32_t)(((int64_t)lkey * p.ldv + cv * 8) * 2);
     const int64_t k32b = 64 * p.ldk, v32b = 64 * p.ldv;
-    auto kdma = [&](int tile, int stage) {
+    auto kdma = [&](int tile, int stage) __attribute__((always_inline)) {
         char* ks = smem + stage * STG + wave * 8 * 128;
         if ((tile + 1) * KT <= p.Nk) {
             const char* kt_ = kU + (int64_t)tile * 2 * k32b;
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(NW * 64, 2) void hk_attn_pipe_kernel(const AttnPara
             }
         }
     };
-    auto vdma = [&](int tile, int stage) {
+    auto vdma = [&](int tile, int stage) __attribute__((always_inline)) {
         char* vs = smem + (2 + stage) * STG + wave * 8 * 128;
         if ((tile + 1) * KT <= p.Nk) {
             const char* vt_ = vU + (int64_t)tile * 2 * v32b;
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(NW * 64, 2) void hk_attn_pipe_kernel(const AttnPara
     // -m_run in 16 registers: the initial accumulator (srcC) of every Q.K^T chain; rebuilt only when m_run moves.
     // Built through asm so the compiler keeps the block instead of re-materialising it with 8 moves per tile.
     f32x16 cneg;
-    auto set_cneg = [&]() {
+    auto set_cneg = [&]() __attribute__((always_inline)) {
         typedef __attribute__((ext_vector_type(2))) float f32x2;
         const f32x2 negm2 = {-m_run, -m_run};
 #pragma unroll
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(NW * 64, 2) void hk_attn_pipe_kernel(const AttnPara
 #define HK_STAMP(i) do {} while (0)
 #endif
 
-    auto rowmax = [&](const f32x16 (&st)[2]) {
+    auto rowmax = [&](const f32x16 (&st)[2]) __attribute__((always_inline)) {
         float mx = fmaxf(st[0][0], st[0][1]);
 #pragma unroll
         for (int i = 2; i < 16; i += 2) mx = fmaxf(mx, fmaxf(st[0][i], st[0][i + 1]));
@@ -652,7 +652,7 @@ __global__ __launch_bounds__(NW * 64, 2) void hk_attn_pipe_kernel(const AttnPara
         for (int i = 0; i < 16; i += 2) mx = fmaxf(mx, fmaxf(st[1][i], st[1][i + 1]));
         return half_swap_max(mx);
     };
-    auto mask_ragged = [&](f32x16 (&st)[2], const int t) {
+    auto mask_ragged = [&](f32x16 (&st)[2], const int t) __attribute__((always_inline)) {
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -717,7 +717,7 @@ __global__ __launch_bounds__(NW * 64, 2) void hk_attn_pipe_kernel(const AttnPara
     const bf16x2 ones2 = __builtin_bit_cast(bf16x2, 0x3f803f80u);
 
     // sc: S(t) (raw, relative to m_run); sn: receives S(t + 1).  PAR = t & 1.
-    auto iter = [&](const int t, f32x16 (&sc)[2], f32x16 (&sn)[2], auto has_next_c, auto next_ragged_c, auto par_c) {
+    auto iter = [&](const int t, f32x16 (&sc)[2], f32x16 (&sn)[2], auto has_next_c, auto next_ragged_c, auto par_c) __attribute__((always_inline)) {
         constexpr bool HAS_NEXT = decltype(has_next_c)::value;
         constexpr bool NEXT_RAGGED = decltype(next_ragged_c)::value;
         constexpr int PAR = decltype(par_c)::value;
@@ -733,7 +733,7 @@ __global__ __launch_bounds__(NW * 64, 2) void hk_attn_pipe_kernel(const AttnPara
         HK_STAMP(0);
         uint32_t pw[16];
         float rs0, rs1;
-        auto exp_chunk = [&](const int g) {  // score registers 4g .. 4g+3 of the 32
+        auto exp_chunk = [&](const int g) __attribute__((always_inline)) {  // score registers 4g .. 4g+3 of the 32
             const int kt = g >> 2, i0 = 4 * (g & 3);
             const float e0 = __builtin_amdgcn_exp2f(sc[kt][i0]);
             const float e1 = __builtin_amdgcn_exp2f(sc[kt][i0 + 1]);
@@ -805,7 +805,7 @@ __global__ __launch_bounds__(NW * 64, 2) void hk_attn_pipe_kernel(const AttnPara
         l_run += rs;
 
         if (PRIO & 1) __builtin_amdgcn_s_setprio(2);
-        auto pv = [&](const int s_) {
+        auto pv = [&](const int s_) __attribute__((always_inline)) {
             u32x4 w;
 #pragma unroll
             for (int j = 0; j < 4; ++j) w[j] = pw[4 * s_ + j];
@@ -849,7 +849,7 @@ __global__ __launch_bounds__(NW * 64, 2) void hk_attn_pipe_kernel(const AttnPara
     using F_ = std::false_type;
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
-    auto run = [&](const int t, auto has_next_c, auto next_ragged_c) {
+    auto run = [&](const int t, auto has_next_c, auto next_ragged_c) __attribute__((always_inline)) {
         if (t & 1) iter(t, sb, sa, has_next_c, next_ragged_c, S1{});
         else iter(t, sa, sb, has_next_c, next_ragged_c, S0{});
     };
