@@ -929,7 +929,9 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
         const long rem = tiles256 % ncu;
         GemmParams tail = p;
         tail.M = 0;
-        if (split && rem != 0 && rem < ncu / 2 && tiles256 >= 2 * ncu) {
+        // HK_GEMM_SPLIT_MAX: largest partial round (in tiles) that still goes to the second launch (default: under half a chip)
+        static const int split_max = getenv("HK_GEMM_SPLIT_MAX") ? atoi(getenv("HK_GEMM_SPLIT_MAX")) : ncu / 2 - 1;
+        if (split && rem != 0 && rem <= split_max && tiles256 >= 2 * ncu) {
             const int rows_main = (int)((tiles256 - rem) / nbn);   // whole tile rows inside the full rounds
             if (rows_main > 0 && rows_main < nbm) {
                 tail.m_off = rows_main * 256;
