@@ -123,10 +123,9 @@ __device__ __forceinline__ f32x4 load_res4(const GemmParams& p, int64_t off) {
 }
 
 // One lane's 4 consecutive output columns of one row: bias, column scale, activation, residual, store.
-__device__ __forceinline__ f32x4 epi_store(const GemmParams& p, f32x4 v, const f32x4 bias, int n, int64_t coff,
-                                           int64_t roff, float rs, float rm) {
+__device__ __forceinline__ f32x4 epi_store(const GemmParams& p, f32x4 v, const f32x4 bias, const f32x4 cc, const f32x4 res,
+                                           int n, int64_t coff, float rs, float rm) {
     if (p.row_stats) {  // LayerNorm folded: rstd * acc + (bias' - rstd * mean * colsum)
-        const f32x4 cc = *reinterpret_cast<const f32x4*>(p.col_c + n);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], rs, __builtin_fmaf(-rm, cc[e], bias[e]));
     } else {
@@ -134,7 +133,7 @@ __device__ __forceinline__ f32x4 epi_store(const GemmParams& p, f32x4 v, const f
     }
     if (p.scale_cols != 0 && n < p.scale_cols) v *= p.scale;
     if (p.act == HK_ACT_GELU_ERF) v = p.out_f32 ? gelu_erf4(v) : gelu_erf4_bf16dst(v);
-    if (p.res) v += load_res4(p, roff + n);
+    if (p.res) v += res;
     if (p.out_f32) {
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + coff + n) = v;
     } else {
@@ -680,6 +679,44 @@ __global__ __launch_bounds__(WM* WN * 64) void hk_gemm_kernel(const GemmParams p
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // ---- epilogue operands (bias, column sums, row statistics, residual) requested BEFORE the K loop, raw, with clamped
+    // indices: they are the oldest entries of the vmcnt queue, land with K-tile 0, and the epilogue of these
+    // latency-bound launches no longer walks through one memory round trip per 16-row group.  Lane owns row
+    // (lane & 15) of each 16-row tile and 4 consecutive columns.
+    const int ncol = n0 + wn * TN + (lane >> 4) * 4;
+    f32x4 bias[NJ], ccv[NJ];
+    float rsv[MI], meanv[MI];
+    u32x4 resraw[MI][NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int nc = min(ncol + j * 16, p.N - 4);
+        bias[j] = p.bias != nullptr ? *reinterpret_cast<const f32x4*>(p.bias + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
+        ccv[j] = p.row_stats != nullptr ? *reinterpret_cast<const f32x4*>(p.col_c + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int mc = min(m0 + wm * TM + i * 16 + (lane & 15), p.M - 1) + p.m_off;
+        rsv[i] = 1.f;
+        meanv[i] = 0.f;
+        if (p.row_stats) {
+            meanv[i] = p.row_stats[2 * (int64_t)mc];
+            rsv[i] = p.row_stats[2 * (int64_t)mc + 1];
+        }
+        if (p.res) {
+            const int64_t roff = p.r.off(mc);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int nc = min(ncol + j * 16, p.N - 4);
+                if (p.res_bf16) {
+                    const u32x2 w = *reinterpret_cast<const u32x2*>(reinterpret_cast<const __bf16*>(p.res) + roff + nc);
+                    resraw[i][j] = u32x4{w[0], w[1], 0u, 0u};
+                } else {
+                    resraw[i][j] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const float*>(p.res) + roff + nc);
+                }
+            }
+        }
+    }
+
     const int KT = p.K / BK;
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
@@ -713,33 +750,24 @@ __global__ __launch_bounds__(WM* WN * 64) void hk_gemm_kernel(const GemmParams p
         slot = slot + 1 == STAGES ? 0 : slot + 1;
     }
 
-    // ---- epilogue: lane owns row (lane & 15) of each 16-row tile and 4 consecutive columns ----
-    const int ncol = n0 + wn * TN + (lane >> 4) * 4;
-    f32x4 bias[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int n = ncol + j * 16;
-        bias[j] = (p.bias != nullptr && n < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + n)
-                                                 : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    // ---- epilogue (operands requested before the K loop) ----
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = m0 + wm * TM + i * 16 + (lane & 15);
         if (m >= p.M) continue;
         const int64_t coff = p.c.off(m + p.m_off);
-        const int64_t roff = p.res ? p.r.off(m + p.m_off) : 0;
-        float rs = 1.f, rm = 0.f;
-        if (p.row_stats) {
-            const float mean = p.row_stats[2 * (int64_t)(m + p.m_off)];
-            rs = p.row_stats[2 * (int64_t)(m + p.m_off) + 1];
-            rm = rs * mean;
-        }
+        const float rs = rsv[i], rm = rsv[i] * meanv[i];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int n = ncol + j * 16;
             if (n < p.N) {
-                const f32x4 v = epi_store(p, acc[i][j], bias[j], n, coff, roff, rs, rm);
+                f32x4 res = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (p.res) {
+                    const u32x4 w = resraw[i][j];
+                    res = p.res_bf16 ? f32x4{bf16_lo(w[0]), bf16_hi(w[0]), bf16_lo(w[1]), bf16_hi(w[1])} : __builtin_bit_cast(f32x4, w);
+                }
+                const f32x4 v = epi_store(p, acc[i][j], bias[j], ccv[j], res, n, coff, rs, rm);
                 s1 += (v[0] + v[1]) + (v[2] + v[3]);
                 s2 = __builtin_fmaf(v[0], v[0], __builtin_fmaf(v[1], v[1], __builtin_fmaf(v[2], v[2], __builtin_fmaf(v[3], v[3], s2))));
             }
