@@ -432,19 +432,23 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
             if (EPI == 2 || EPI == 4) {
                 // bf16 residual stream updated in place: a lane owns 8 consecutive columns (16 B of bf16)
                 // of rows 8 it + (lane >> 3); two staged fp32 chunks + one 16-B residual load per store.
-                u32x4 rcur[2], rnxt[2];
-                auto res_load8 = [&](int rnd, u32x4(&rr)[2]) {
+                // The residual rows of round r + PF are requested before round r is staged; the loads are unconditional
+                // (row clamped, N is a multiple of 256 here) so the compiler can count its waits instead of draining
+                // the queue.  HK_EPI_PF (compile time): prefetch distance in rounds.
+#ifndef HK_EPI_PF
+#define HK_EPI_PF 3
+#endif
+                constexpr int PF = HK_EPI_PF;
+                u32x4 rr[PF + 1][2];
+                auto res_load8 = [&](int rnd, u32x4(&dst)[2]) __attribute__((always_inline)) {
 #pragma unroll
                     for (int it = 0; it < 2; ++it) {
-                        const int m = mw + rnd * 16 + it * 8 + (lane >> 3), n = nw + (lane & 7) * 8;
-                        // (kept inside the bounds branch: with unconditional, row-clamped loads the compiler counts its
-                        // waits -- vmcnt(3) / (2) instead of (0) -- and proj / fc2 measured 1.7 % SLOWER in situ)
-                        rr[it] = (m < p.M && n < p.N)
-                                     ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const __bf16*>(p.res) + p.r.off(m) + n)
-                                     : u32x4{0u, 0u, 0u, 0u};
+                        const int m = min(mw + rnd * 16 + it * 8 + (lane >> 3), p.M - 1), n = nw + (lane & 7) * 8;
+                        dst[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const __bf16*>(p.res) + p.r.off(m) + n);
                     }
                 };
-                res_load8(0, rcur);
+#pragma unroll
+                for (int q = 0; q < PF; ++q) res_load8(q, rr[q]);
 #pragma unroll
                 for (int rnd = 0; rnd < 8; ++rnd) {
                     const int mh = rnd >> 2, i = rnd & 3;
@@ -455,14 +459,14 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
                             const int ch = nh * 8 + j * 4 + g4;
                             *reinterpret_cast<f32x4*>(stg + r16 * 256 + ((ch ^ r16) << 4)) = pre(acc[mh][nh][i][j], nh, j, mh, i);
                         }
-                    if (rnd < 7) res_load8(rnd + 1, rnxt);
+                    if (rnd + PF < 8) res_load8(rnd + PF, rr[(rnd + PF) % (PF + 1)]);
 #pragma unroll
                     for (int it = 0; it < 2; ++it) {
                         const int row = it * 8 + (lane >> 3), c8 = lane & 7;
                         const f32x4 a = *reinterpret_cast<const f32x4*>(stg + row * 256 + (((2 * c8) ^ row) << 4));
                         const f32x4 b = *reinterpret_cast<const f32x4*>(stg + row * 256 + (((2 * c8 + 1) ^ row) << 4));
                         const int m = mw + rnd * 16 + row, n = nw + c8 * 8;
-                        const u32x4 r = rcur[it];
+                        const u32x4 r = rr[rnd % (PF + 1)][it];
                         const float v0 = a[0] + bf16_lo(r[0]), v1 = a[1] + bf16_hi(r[0]), v2 = a[2] + bf16_lo(r[1]),
                                     v3 = a[3] + bf16_hi(r[1]), v4 = b[0] + bf16_lo(r[2]), v5 = b[1] + bf16_hi(r[2]),
                                     v6 = b[2] + bf16_lo(r[3]), v7 = b[3] + bf16_hi(r[3]);
@@ -494,8 +498,6 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
                             *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(p.C) + p.c.off(m) + n) = o;
                         }
                     }
-#pragma unroll
-                    for (int it = 0; it < 2; ++it) rcur[it] = rnxt[it];
                 }
                 return;
             }
