@@ -39,6 +39,11 @@ class _Plan:
         self.patch_desc: Optional[L.HkGemmDesc] = None
         self.vit_end = 0                   # steps[:vit_end] = the ViT up to vision_layernorm (what training reuses)
         self.graphs: Dict[Tuple, "torch.cuda.CUDAGraph"] = {}   # captured calls, keyed by (input kind, table, norm)
+        # Q-Former text-branch FFN of each layer, free to run beside the query branch on a second stream:
+        # (fork, start, end) step indices -- the fork point is right after the self-attention LayerNorm, steps
+        # [start, end) are the branch, the main stream joins before step `end`
+        self.side: List[Tuple[int, int, int]] = []
+        self.side_events: List = []
 
     def buf(self, name, shape, dtype, device):
         t = torch.empty(shape, dtype=dtype, device=device)
@@ -72,6 +77,9 @@ class HipEncoderEngine:
         # the host-side enqueue it removes was already hidden behind the GPU.  Kept for callers that want the
         # host thread free.
         self.use_graphs = os.environ.get("HK_GRAPH", "0") == "1"
+        # HK_SIDE_STREAM=0: the Q-Former text-branch FFN runs in line on the caller's stream (A/B aid)
+        self.side_stream = os.environ.get("HK_SIDE_STREAM", "1") != "0"
+        self._side: Optional["torch.cuda.Stream"] = None
         # norm1 / norm2 of the ViT blocks folded into the qkv / fc1 GEMMs (statistics pass + row terms in the GEMM
         # epilogue instead of a LayerNorm pass that writes its output); needs the bf16 residual stream the statistics
         # kernel reads.  HK_FOLD_LN=0 keeps the standalone LayerNorm (A/B aid).
@@ -233,7 +241,9 @@ class HipEncoderEngine:
             cctx = plan.buf("cctx", (B * nq, d), bf16, dev)
             cf = plan.buf("cf", (B * nq, d), f32, dev)
             cb = plan.buf("cb", (B * nq, d), bf16, dev)
-            fh = plan.buf("fh", (B * max(nq, Lt), inter), bf16, dev)
+            fh = plan.buf("fh", (B * nq, inter), bf16, dev)
+            fht = plan.buf("fh_t", (B * max(Lt, 1), inter), bf16, dev)   # text-branch temporaries of their own: the branch
+            tft = plan.buf("tf_t", (B * max(Lt, 1), d), f32, dev)         # may run beside the query branch (plan.side)
             out = plan.buf("out", (B * nq, cfg.llama_hidden), f32, dev)
 
         P = lambda t: t.data_ptr()  # noqa: E731
@@ -319,6 +329,7 @@ class HipEncoderEngine:
             self._gemm(plan, P(ctx), w[o + "ao.w"], P(tf), B * S, d, d, bias=P(w[o + "ao.b"]), residual=P(hf),
                        a_rows=plain(d), c_rows=plain(d), r_rows=plain(d), out_f32=True)
             self._ln(plan, P(tf), True, w[o + "ao.g"], w[o + "ao.bt"], P(ab), P(af), B * S, d, cfg.qf_ln_eps)
+            fork = len(plan.steps)
             if i % cfg.cross_attention_freq == 0:
                 self._gemm(plan, P(ab), w[o + "cq.w"], P(cq), B * nq, d, d, bias=P(w[o + "cq.b"]),
                            a_rows=qrows, c_rows=plain(d), scale_cols=d, scale=qscale)
@@ -341,12 +352,16 @@ class HipEncoderEngine:
             # text-branch FFN (Qformer.py:509-512); its last-layer result is never read (hawkeye_it.py:269)
             if Lt > 0 and not last:
                 toff = nq * d
-                self._gemm(plan, P(ab) + toff * eb, w[o + "ti.w"], P(fh), B * Lt, inter, d, bias=P(w[o + "ti.b"]),
+                start = len(plan.steps)
+                self._gemm(plan, P(ab) + toff * eb, w[o + "ti.w"], P(fht), B * Lt, inter, d, bias=P(w[o + "ti.b"]),
                            a_rows=trows, c_rows=plain(inter), act=L.HK_ACT_GELU_ERF)
-                self._gemm(plan, P(fh), w[o + "to.w"], P(tf), B * Lt, d, inter, bias=P(w[o + "to.b"]),
+                self._gemm(plan, P(fht), w[o + "to.w"], P(tft), B * Lt, d, inter, bias=P(w[o + "to.b"]),
                            residual=P(af) + toff * 4, a_rows=plain(inter), c_rows=plain(d), r_rows=trows, out_f32=True)
-                self._ln(plan, P(tf), True, w[o + "to.g"], w[o + "to.bt"], P(hb) + toff * eb, P(hf) + toff * 4,
+                self._ln(plan, P(tft), True, w[o + "to.g"], w[o + "to.bt"], P(hb) + toff * eb, P(hf) + toff * 4,
                          B * Lt, d, cfg.qf_ln_eps, out_rows=trows)
+                # reads rows [nq:] of ab / af (complete at `fork`), writes rows [nq:] of hb / hf (read by the next
+                # layer's qkv GEMM, the step after `end`); the query branch touches rows [:nq] only
+                plan.side.append((fork, start, len(plan.steps)))
         # llama_proj on the query rows (hawkeye_it.py:269)
         self._tag = "llama_proj"
         self._gemm(plan, P(hb), w["proj.w"], P(out), B * nq, cfg.llama_hidden, d, bias=P(w["proj.b"]),
@@ -453,7 +468,34 @@ class HipEncoderEngine:
             L.check(self.lib.hk_patchify_bf16(image.data_ptr(), ws["patches"].data_ptr(), B, T, H, W,
                                               cfg.patch_size, stream), "hk_patchify_bf16")
         plan.patch_desc.residual = pos_embed.data_ptr()
-        if profile is None:
+        if profile is None and upto is None and self.side_stream and plan.side:
+            # text-branch segments on the side stream: fork event recorded on the main stream at the fork point, the
+            # segment waits for it, the main stream waits for the segment's end event before the step that follows it
+            main = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            side, side_h = self._side, self._side.cuda_stream
+            while len(plan.side_events) < 2 * len(plan.side):
+                plan.side_events.append(torch.cuda.Event())
+            forks = {f: k for k, (f, _, _) in enumerate(plan.side)}
+            starts = {a: k for k, (_, a, _) in enumerate(plan.side)}
+            ends = {e: k for k, (_, _, e) in enumerate(plan.side)}
+            cur = None
+            for idx, (fn, args, name, _) in enumerate(plan.steps):
+                if idx in ends:
+                    k = ends[idx]
+                    plan.side_events[2 * k + 1].record(side)
+                    main.wait_event(plan.side_events[2 * k + 1])
+                    cur = None
+                if idx in forks:
+                    plan.side_events[2 * forks[idx]].record(main)
+                if idx in starts:
+                    cur = starts[idx]
+                    side.wait_event(plan.side_events[2 * cur])
+                rc = fn(*args, side_h if cur is not None else stream)
+                if rc != 0:
+                    L.check(rc, name)
+        elif profile is None:
             for fn, args, name, _ in plan.steps[:upto]:
                 rc = fn(*args, stream)
                 if rc != 0:
