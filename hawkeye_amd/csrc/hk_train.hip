@@ -8,6 +8,7 @@
 // site `site` is kept iff fmix32(idx ^ key(seed, site)) >= p * 2^32.  The backward regenerates the mask from the
 // same (seed, site, idx), so no mask is ever stored.
 #include "hk_common.h"
+#include <mutex>
 
 namespace {
 
@@ -820,11 +821,9 @@ extern "C" int hk_drop_add_ln(const float* t, const float* res, const hk_rows* r
     return HK_OK;
 }
 
-extern "C" int hk_colsum(const void* x, int32_t dtype, int64_t ld, int64_t R, int32_t C, float* out, float* ws,
-                         void* stream) {
-    HK_REQUIRE(x && out && R > 0 && C > 0 && ld >= C, "hk_colsum: bad arguments");
-    HK_REQUIRE(dtype == HK_DT_BF16 || dtype == HK_DT_F32, "hk_colsum: unknown dtype %d", dtype);
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+// the two launches of hk_colsum; ws == nullptr: one launch, no partials
+static int colsum_launch(const void* x, int32_t dtype, int64_t ld, int64_t R, int32_t C, float* out, float* ws,
+                         hipStream_t s, const char* who) {
     int nsplit = (int)(R / 256);
     nsplit = nsplit < 1 ? 1 : (nsplit > HK_COLSUM_MAX_SPLIT ? HK_COLSUM_MAX_SPLIT : nsplit);
     if (!ws) nsplit = 1;
@@ -832,13 +831,58 @@ extern "C" int hk_colsum(const void* x, int32_t dtype, int64_t ld, int64_t R, in
     const dim3 grid((C + 63) / 64, nsplit);
     if (dtype == HK_DT_BF16) hipLaunchKernelGGL((colsum_kernel<true>), grid, dim3(256), 0, s, x, ld, R, C, first);
     else hipLaunchKernelGGL((colsum_kernel<false>), grid, dim3(256), 0, s, x, ld, R, C, first);
-    HK_CHECK_LAUNCH("hk_colsum");
+    HK_CHECK_LAUNCH(who);
     if (nsplit > 1) {
         hipLaunchKernelGGL((colsum_kernel<false>), dim3((C + 63) / 64, 1), dim3(256), 0, s, (const void*)ws, (int64_t)C,
                            (int64_t)nsplit, C, out);
-        HK_CHECK_LAUNCH("hk_colsum(2)");
+        HK_CHECK_LAUNCH(who);
     }
     return HK_OK;
+}
+
+extern "C" int hk_colsum(const void* x, int32_t dtype, int64_t ld, int64_t R, int32_t C, float* out, float* ws,
+                         void* stream) {
+    HK_REQUIRE(x && out && R > 0 && C > 0 && ld >= C, "hk_colsum: bad arguments");
+    HK_REQUIRE(dtype == HK_DT_BF16 || dtype == HK_DT_F32, "hk_colsum: unknown dtype %d", dtype);
+    return colsum_launch(x, dtype, ld, R, C, out, ws, reinterpret_cast<hipStream_t>(stream), "hk_colsum");
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// hk_colsum_static: hk_colsum for callers that cannot allocate.  The [HK_COLSUM_MAX_SPLIT, C] partial sums of the
+// two-stage reduction live in a file-scope device array; every GPU the library runs on holds its own copy
+// (2.25 MiB) until the process ends.  In host code the array's NAME is only a stand-in for the symbol: the device
+// address is looked up once per device (hipGetSymbolAddress with that device current) and only that pointer is
+// ever handed to a kernel.  The first launch writes every partial the second one reads, so nothing has to be
+// cleared between calls; two calls in flight on one GPU at the same time share the array and race.
+// ------------------------------------------------------------------------------------------------------------
+static __device__ __align__(256) float scratch[(size_t)HK_COLSUM_MAX_SPLIT * HK_COLSUM_STATIC_MAX_C];
+
+#define HK_MAX_DEVICES 64
+static std::mutex g_scratch_mu;
+static float* g_scratch_ptr[HK_MAX_DEVICES];   // device address of `scratch` on device i, nullptr = not looked up yet
+
+extern "C" int hk_colsum_static(const void* x, int32_t dtype, int64_t ld, int64_t R, int32_t C, float* out,
+                                void* stream) {
+    HK_REQUIRE(x && out && R > 0 && C > 0 && ld >= C, "hk_colsum_static: bad arguments");
+    HK_REQUIRE(dtype == HK_DT_BF16 || dtype == HK_DT_F32, "hk_colsum_static: unknown dtype %d", dtype);
+    HK_REQUIRE(C <= HK_COLSUM_STATIC_MAX_C, "hk_colsum_static: C=%d exceeds the static scratch (at most %d columns); "
+               "use hk_colsum with a caller-provided workspace", C, HK_COLSUM_STATIC_MAX_C);
+    int dev = -1;
+    HK_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < HK_MAX_DEVICES,
+               "hk_colsum_static: no current HIP device (or device index >= %d)", HK_MAX_DEVICES);
+    float* ws;
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mu);
+        ws = g_scratch_ptr[dev];
+        if (!ws) {
+            void* p = nullptr;
+            const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+            HK_REQUIRE(e == hipSuccess && p, "hk_colsum_static: hipGetSymbolAddress failed on device %d: %s", dev,
+                       hipGetErrorString(e));
+            ws = g_scratch_ptr[dev] = static_cast<float*>(p);
+        }
+    }
+    return colsum_launch(x, dtype, ld, R, C, out, ws, reinterpret_cast<hipStream_t>(stream), "hk_colsum_static");
 }
 
 extern "C" int hk_layernorm_bwd(const float* dy, const hk_rows* dy_rows, const float* z, const float* gamma,

@@ -67,6 +67,7 @@ class HkAttnTrainDesc(C.Structure):
 
 HK_LNBWD_MAX_BLOCKS = 256
 HK_COLSUM_MAX_SPLIT = 64
+HK_COLSUM_STATIC_MAX_C = 9216
 
 # every symbol include/hawkeye_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
@@ -102,6 +103,7 @@ SYMBOLS = {
                                    C.POINTER(HkDropout), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
     "hk_colsum": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hk_colsum_static": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "hk_transpose_bf16": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(HkRows), C.c_int64, C.c_int32, C.c_void_p,
                                     C.c_int64, C.c_void_p]),
     "hk_gelu_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -260,6 +260,17 @@ int hk_layernorm_bwd(const float* dy, const hk_rows* dy_rows, const float* z, co
 #define HK_COLSUM_MAX_SPLIT 64
 int hk_colsum(const void* x, int32_t dtype, int64_t ld, int64_t R, int32_t C, float* out, float* ws, void* stream);
 
+/* hk_colsum for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc).  No counterpart in the reference.  Same result, bit for bit, as hk_colsum with a workspace; the
+ * [HK_COLSUM_MAX_SPLIT, C] partial sums live in a static device array of the library (2.25 MiB per GPU, held until
+ * the process ends) instead of a caller workspace.  C <= HK_COLSUM_STATIC_MAX_C, otherwise HK_EINVAL.  Calls no
+ * hipMalloc / hipFree.  Every call on a GPU shares that GPU's array: calls that overlap in time on one GPU (two
+ * streams, two threads) race -- serialise them, or give the others hk_colsum with a workspace of their own.  The
+ * array's device address is looked up on the first call on each device (hipGetSymbolAddress; the device that is
+ * current at the call must be the one `stream` belongs to) -- make that first call outside graph capture. */
+#define HK_COLSUM_STATIC_MAX_C 9216
+int hk_colsum_static(const void* x, int32_t dtype, int64_t ld, int64_t R, int32_t C, float* out, void* stream);
+
 /* out bf16 [C, ldo]: out[c][r] = x[r][c] for r < R, 0 for R <= r < roundup(R, 64).  x bf16 or fp32, rows mapped by
  * x_rows (NULL = plain [R, C]).  Makes the contraction-contiguous operands of the backward GEMMs:
  *   dgrad  dX = dY . W      -> hk_gemm_bf16(A = dY,   W = W^T  [in, out])
