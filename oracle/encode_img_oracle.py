@@ -243,7 +243,12 @@ def encode_img(sd, cfg, image, input_ids, text_mask, pos_embed, stages=None, dro
         qt = torch.cat([qt, sd["extra_query_tokens"]], dim=1)         # :237-238
     qt = qt.expand(B, -1, -1)                                         # :241
     nq = qt.shape[1]
-    atts = torch.cat([torch.ones(B, nq, dtype=torch.long), text_mask], dim=1)   # :250-251
+    if input_ids is not None:
+        atts = torch.cat([torch.ones(B, nq, dtype=torch.long), text_mask], dim=1)   # :250-251
+    else:
+        # qformer_text_input=False (:261-267): no ids, no mask -> BertModel.forward builds an all-ones mask over
+        # the query rows (Qformer.py:912-915)
+        atts = torch.ones(B, nq, dtype=torch.long)
     hidden = qformer_forward(sd, cfg, input_ids, atts, qt, emb, stages, drop)    # :253-260
     out = F.linear(hidden[:, :nq, :], sd["llama_proj.weight"], sd["llama_proj.bias"])  # :269
     return out, use_image

@@ -21,6 +21,7 @@ all in memory, none touching the reference checkout:
      fixture's frames are generated at the final resolution.
 
 Usage:  python oracle/make_goldens.py            (writes tests/golden/)
+        python oracle/make_goldens.py round2     (only full_T12_B2 + small_video_notext, added in round 2)
         python oracle/make_goldens.py train      (only the row f2 training fixture)
 """
 import importlib.machinery
@@ -170,10 +171,15 @@ def reference_encode_img_grad(m, image, input_ids, text_mask, stages=None):
     query_tokens = torch.cat([m.query_tokens, m.extra_query_tokens], dim=1)
     query_tokens = query_tokens.expand(image_embeds.shape[0], -1, -1)
     query_atts = torch.ones(query_tokens.size()[:-1], dtype=torch.long)
-    qformer_atts = torch.cat([query_atts, text_mask], dim=1)
-    query_output = m.qformer.bert(
-        input_ids, attention_mask=qformer_atts, query_embeds=query_tokens,
-        encoder_hidden_states=image_embeds, encoder_attention_mask=image_atts, return_dict=True)
+    if input_ids is not None:                       # qformer_text_input=True, hawkeye_it.py:242-260
+        qformer_atts = torch.cat([query_atts, text_mask], dim=1)
+        query_output = m.qformer.bert(
+            input_ids, attention_mask=qformer_atts, query_embeds=query_tokens,
+            encoder_hidden_states=image_embeds, encoder_attention_mask=image_atts, return_dict=True)
+    else:                                           # qformer_text_input=False, hawkeye_it.py:261-267
+        query_output = m.qformer.bert(
+            query_embeds=query_tokens, encoder_hidden_states=image_embeds, encoder_attention_mask=image_atts,
+            return_dict=True)
     out = m.llama_proj(query_output.last_hidden_state[:, :query_tokens.size(1), :])
     for h in hooks:
         h.remove()
@@ -198,7 +204,7 @@ def run_case(name, cfg: EncoderConfig, B, T, Lt, seed, ragged, full_tensors, ref
     sd = W.make_state_dict(cfg, seed)
     m = build_reference(cfg, sd, ref_vit, ref_qf)
     image = W.make_clip(B, T, cfg.img_size, seed)
-    ids, mask = W.make_instruction_ids(B, Lt, cfg.qf_vocab, seed, ragged)
+    ids, mask = W.make_instruction_ids(B, Lt, cfg.qf_vocab, seed, ragged) if Lt > 0 else (None, None)
     enc = m.vision_encoder.encoder
     L = cfg.patches_per_frame
     if T == 1:
@@ -211,7 +217,9 @@ def run_case(name, cfg: EncoderConfig, B, T, Lt, seed, ragged, full_tensors, ref
     stages = {}
     out, use_image = reference_encode_img(m, image, ids, mask, stages)
     rec = dict(B=np.int64(B), T=np.int64(T), Lt=np.int64(Lt), seed=np.int64(seed), ragged=np.int64(ragged),
-               use_image=np.int64(use_image), input_ids=ids.numpy(), text_mask=mask.numpy())
+               use_image=np.int64(use_image))
+    if Lt > 0:
+        rec.update(input_ids=ids.numpy(), text_mask=mask.numpy())
     if full_tensors:
         rec["out"] = out.numpy()
         for k, v in stages.items():
@@ -417,6 +425,15 @@ def main():
         train_goldens(ref_vit, ref_qf, outdir)
         return
     ref_vit, ref_qf = _import_reference()
+    if sys.argv[1:] == ["round2"]:
+        # added in round 2 (the fixtures of round 1 are left as committed): the shipped default frame count
+        # (scripts/train/config_7b_stage3.py:13, tasks/test.py:584) with a ragged text mask, and the
+        # qformer_text_input=False branch (hawkeye_it.py:261-267) at the reduced shape
+        run_case("full_T12_B2", FULL, B=2, T=12, Lt=20, seed=8, ragged=True, full_tensors=False,
+                 ref_vit=ref_vit, ref_qf=ref_qf, outdir=outdir)
+        run_case("small_video_notext", SMALL, B=2, T=2, Lt=0, seed=9, ragged=False, full_tensors=True,
+                 ref_vit=ref_vit, ref_qf=ref_qf, outdir=outdir)
+        return
     pos_embed_goldens(ref_vit, outdir)
     frame_transform_goldens(outdir)
     llm_goldens(outdir)

@@ -72,7 +72,7 @@ def test_small_fixture_all_visible_stages(golden_dir, name):
     _check("vision_layernorm", ws["xn"].float().view(B, -1, SMALL.encoder_embed_dim), g["stage.vision_layernorm"])
 
 
-@pytest.mark.parametrize("name", ["full_T8_B1", "full_T1_B2", "full_T16_B1"])
+@pytest.mark.parametrize("name", ["full_T8_B1", "full_T1_B2", "full_T12_B2", "full_T16_B1"])
 def test_full_size_goldens(golden_dir, name):
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     B, T, seed = int(g["B"]), int(g["T"]), int(g["seed"])
@@ -89,6 +89,137 @@ def test_full_size_goldens(golden_dir, name):
         _check(f"{name}.{stage}.slice", buf[rows][:, cols], g[f"digest.{stage}.slice"])
         l2 = float(g[f"digest.{stage}.l2"])
         assert abs(buf.double().norm().item() - l2) <= 1e-2 * l2
+    # the last Q-Former layer's hidden state: the query rows of the digest slice (the text rows of the last layer are
+    # never computed on this path: hawkeye_it.py:269 reads [:, :96] only)
+    S = 96 + ids.shape[1]
+    stage = f"qf_layer_{FULL.qf_layers - 1}"
+    rows = g[f"digest.{stage}.rows"]
+    keep = np.nonzero(rows % S < 96)[0]
+    assert len(keep) >= 2
+    cols = torch.from_numpy(g[f"digest.{stage}.cols"]).to(DEV)
+    got = ws["hf"][torch.from_numpy(rows[keep]).to(DEV)][:, cols]
+    _check(f"{name}.{stage}.query_rows", got, g[f"digest.{stage}.slice"][keep])
+
+
+def test_no_text_branch_matches_reference(golden_dir):
+    """qformer_text_input=False (hawkeye_it.py:65-70, 261-267): the Q-Former sees the 96 query rows only (Lt = 0);
+    golden from the reference modules called without input_ids."""
+    g = np.load(os.path.join(golden_dir, "small_video_notext.npz"))
+    B, T, seed = int(g["B"]), int(g["T"]), int(g["seed"])
+    assert int(g["Lt"]) == 0
+    m = _model(SMALL, seed, T)
+    m.qformer_text_input = False
+    image = W.make_clip(B, T, SMALL.img_size, seed).to(DEV)
+    out, use_image = m.encode_img(image, "ignored: the text never reaches the Q-Former on this branch")
+    assert not use_image
+    _check("notext.out", out, g["out"])
+    ws = m._engine.plans[(B, T, 0)].ws
+    last = SMALL.qf_layers - 1
+    _check("notext.qf_last", ws["hf"].view(B, SMALL.n_query, -1), g[f"stage.qf_layer_{last}"])
+
+
+class _StubBertTokenizer:
+    """BertTokenizer-compatible callable for the call at hawkeye_it.py:243-249 (the real vocabulary files are not
+    available offline): lower-cased whitespace words hashed to ids, [CLS] ... [SEP], padding='longest' with 0,
+    truncation to max_length on the LEFT of the word sequence (truncation_side='left', hawkeye_it.py:55) keeping the
+    special tokens, return_tensors='pt'."""
+
+    def __init__(self, vocab):
+        self.vocab, self.truncation_side = vocab, "left"
+        self.calls = []
+
+    def __call__(self, text, padding=False, truncation=False, max_length=None, return_tensors=None):
+        self.calls.append(dict(padding=padding, truncation=truncation, max_length=max_length, return_tensors=return_tensors))
+        assert return_tensors == "pt"
+        texts = [text] if isinstance(text, str) else list(text)
+        rows = []
+        for t in texts:
+            w = [1000 + (sum(ord(c) * (i + 7) for i, c in enumerate(word)) % (self.vocab - 1100)) for word in t.lower().split()]
+            if truncation and max_length is not None and len(w) + 2 > max_length:
+                w = w[len(w) + 2 - max_length:]
+            rows.append([101] + w + [102])
+        n = max(len(r) for r in rows) if padding == "longest" else None
+        ids = torch.tensor([r + [0] * (n - len(r)) for r in rows], dtype=torch.int64)
+        mask = torch.tensor([[1] * len(r) + [0] * (n - len(r)) for r in rows], dtype=torch.int64)
+        from types import SimpleNamespace
+        enc = SimpleNamespace(input_ids=ids, attention_mask=mask)
+        enc.to = lambda dev: SimpleNamespace(input_ids=ids.to(dev), attention_mask=mask.to(dev))
+        return enc
+
+
+def test_strings_through_the_tokenizer_call(golden_dir):
+    """hawkeye_it.py:243-251: instruction strings -> tokenizer(padding='longest', truncation=True,
+    max_length=max_txt_len, return_tensors='pt') -> ids + mask; same bits as the pre-tokenised call."""
+    cfg, seed, B, T = SMALL, 17, 3, 2
+    m = _model(cfg, seed, T)
+    m.max_txt_len = 8
+    tok = _StubBertTokenizer(cfg.qf_vocab)
+    m.tokenizer = tok
+    text = ["watch the video and answer", "what does the person do after opening the door of the fridge slowly",
+            "hello"]
+    image = W.make_clip(B, T, cfg.img_size, seed).to(DEV)
+    out, _ = m.encode_img(image, text)
+    assert tok.calls[-1] == dict(padding="longest", truncation=True, max_length=8, return_tensors="pt")
+    enc = tok(text, padding="longest", truncation=True, max_length=8, return_tensors="pt")
+    assert enc.input_ids.shape == (B, 8) and int(enc.attention_mask[2].sum()) == 3     # truncated / padded rows
+    assert enc.input_ids[1, 1] != tok(text[1], padding="longest", return_tensors="pt").input_ids[0, 1]   # left side cut
+    out2, _ = m.encode_img(image, (enc.input_ids, enc.attention_mask))
+    assert torch.equal(out, out2)
+    # a single string for a single clip (tasks/test.py:497-499 passes the system prompt as a str)
+    o1, _ = m.encode_img(image[:1], text[0])
+    e1 = tok(text[0], padding="longest", truncation=True, max_length=8, return_tensors="pt")
+    o2, _ = m.encode_img(image[:1], (e1.input_ids, e1.attention_mask))
+    assert torch.equal(o1, o2)
+    # ... and against the oracle on those ids
+    from oracle import encode_img_oracle as O
+    sd = W.make_state_dict(cfg, seed)
+    table = posembed.video_pos_embed(T, cfg.patches_per_frame, cfg.encoder_embed_dim, cfg.ckpt_num_frame)
+    ref, _ = O.encode_img(sd, cfg.to_dict(), image.cpu(), enc.input_ids, enc.attention_mask, table)
+    _check("tokenizer.out", out, ref.numpy())
+
+
+def test_call_under_outer_autocast_is_unchanged():
+    """The trainer and the eval scripts call the model under torch.cuda.amp.autocast (train_it.py:66,
+    tasks/test.py:495); the path's arithmetic is its own, so the result is the same bits, in the default fp16."""
+    cfg, seed = SMALL, 19
+    m = _model(cfg, seed, 2)
+    m.out_dtype = torch.float16
+    image = W.make_clip(2, 2, cfg.img_size, seed).to(DEV)
+    ids, mask = W.make_instruction_ids(2, 5, cfg.qf_vocab, seed, ragged=True)
+    want, _ = m.encode_img(image, (ids, mask))
+    with torch.autocast("cuda", dtype=torch.float16):
+        got, _ = m.encode_img(image, (ids, mask))
+        half, _ = m.encode_img(image.half(), (ids, mask))      # a caller that cast the clip itself
+    assert got.dtype == torch.float16 and torch.equal(got, want)
+    assert _cos(half, want) > 0.9999
+
+
+def test_headline_shape_batch32_T16_clip_independence_and_oracle():
+    """BASELINE config 2 as the bench runs it: B=32, T=16, Lt=32 (M = 100 352 rows: persistent tile list with a
+    partial last round, tail-split second launch, row statistics across 392 row panels).  Size-independent
+    property: a clip's result does not depend on its batch (first and last clip alone == inside the batch);
+    the last clip is also checked against the oracle (one fp32 CPU run)."""
+    from oracle import encode_img_oracle as O
+    cfg, seed, B, T, Lt = FULL, 23, 32, 16, 32
+    sd = W.make_state_dict(cfg, seed)
+    m = HawkEyeEncoder(cfg, out_dtype=torch.float32)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).eval()
+    table = posembed.video_pos_embed(T, cfg.patches_per_frame, cfg.encoder_embed_dim, cfg.ckpt_num_frame)
+    m.vision_encoder.encoder.pos_embed = table
+    gen = torch.Generator(device=DEV).manual_seed(seed)
+    image = torch.randn(B, T, 3, cfg.img_size, cfg.img_size, generator=gen, device=DEV)
+    ids, mask = W.make_instruction_ids(B, Lt, cfg.qf_vocab, seed, ragged=True)
+    out = m.encode_img(image, (ids, mask))[0].clone()
+    assert torch.isfinite(out).all()
+    for b in (0, B - 1):
+        alone, _ = m.encode_img(image[b:b + 1], (ids[b:b + 1], mask[b:b + 1]))
+        c = _cos(alone[0], out[b])
+        print(f"[parity] B32_T16 clip {b}: alone vs in-batch cosine = {c:.7f}")
+        assert c > 0.99999, (b, c)
+    ref, _ = O.encode_img(sd, cfg.to_dict(), image[B - 1:].cpu(), ids[B - 1:], mask[B - 1:], table)
+    _check("B32_T16.clip31 vs oracle", out[B - 1:], ref.numpy())
+    m._engine.plans.clear()        # 4.3 GB of workspace
 
 
 def test_fp32_residual_stream_mode(golden_dir):
