@@ -44,8 +44,8 @@ def read_state(path: str) -> Dict[str, torch.Tensor]:
 
 def load_checkpoints(model, paths: Union[str, Sequence[str]], strict: bool = False) -> Dict[str, List[str]]:
     """Apply checkpoint files in order (later files overwrite earlier ones), like the reference's stacked
-    `load_state_dict(strict=False)` calls.  Returns {"loaded": [...], "missing": [...], "ignored": [...],
-    "mismatched": [...]}: `missing` = hot-path parameters no file provided (left at their initial values),
+    `load_state_dict(strict=False)` calls.  Returns {"loaded": [...], "missing": [...], "ignored": [...]}:
+    `missing` = hot-path parameters no file provided (left at their initial values),
     `ignored` = hot-path-prefixed keys the model does not have (e.g. the 24th ViT block that
     return_index = -2 never builds, models/blip2/vit.py:350).  A shape mismatch always raises, naming the key;
     strict=True also raises on missing keys."""

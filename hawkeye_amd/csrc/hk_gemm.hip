@@ -39,7 +39,7 @@ struct GemmParams {
     void* C;
     const float* row_stats;  // folded LayerNorm of A: [ceil256(M)][2] (mean, rstd) or null
     const float* col_c;      // with row_stats: [N] column sums of W
-    float* row_part;         // out: per row and 64-column group (sum, sum of squares) of C before rounding, or null
+    float* row_part;         // out: per row and 64-column group (sum, sum of squares) of C as stored (bf16), or null
     int M, N, K;
     RowMap a, c, r;
     int64_t ldw;
@@ -141,6 +141,8 @@ __device__ __forceinline__ f32x4 epi_store(const GemmParams& p, f32x4 v, const f
         o[0] = pack_bf16x2(v[0], v[1]);
         o[1] = pack_bf16x2(v[2], v[3]);
         *reinterpret_cast<u32x2*>(reinterpret_cast<__bf16*>(p.C) + coff + n) = o;
+        // the values as stored: row statistics taken from them (row_part) describe exactly the matrix the consumer reads
+        v = f32x4{bf16_lo(o[0]), bf16_hi(o[0]), bf16_lo(o[1]), bf16_hi(o[1])};
     }
     return v;
 }
@@ -470,18 +472,27 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
                         const float v0 = a[0] + bf16_lo(r[0]), v1 = a[1] + bf16_hi(r[0]), v2 = a[2] + bf16_lo(r[1]),
                                     v3 = a[3] + bf16_hi(r[1]), v4 = b[0] + bf16_lo(r[2]), v5 = b[1] + bf16_hi(r[2]),
                                     v6 = b[2] + bf16_lo(r[3]), v7 = b[3] + bf16_hi(r[3]);
+                        u32x4 o;
+                        o[0] = pack_bf16x2(v0, v1);
+                        o[1] = pack_bf16x2(v2, v3);
+                        o[2] = pack_bf16x2(v4, v5);
+                        o[3] = pack_bf16x2(v6, v7);
                         if (EPI == 4) {
                             // LayerNorm statistics of the updated residual stream, for the GEMM that consumes it with
-                            // the norm folded in: (sum, sum of squares) of this wave's 64 columns of the row
-                            float s1 = ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7));
-                            float s2 = v0 * v0;
-                            s2 = __builtin_fmaf(v1, v1, s2);
-                            s2 = __builtin_fmaf(v2, v2, s2);
-                            s2 = __builtin_fmaf(v3, v3, s2);
-                            s2 = __builtin_fmaf(v4, v4, s2);
-                            s2 = __builtin_fmaf(v5, v5, s2);
-                            s2 = __builtin_fmaf(v6, v6, s2);
-                            s2 = __builtin_fmaf(v7, v7, s2);
+                            // the norm folded in: (sum, sum of squares) of this wave's 64 columns of the row -- of the
+                            // bf16 values as STORED, the ones the consumer multiplies: with the mean taken from the
+                            // unrounded sums the folded mean term would not cancel exactly against the MFMA's
+                            const float w0 = bf16_lo(o[0]), w1 = bf16_hi(o[0]), w2 = bf16_lo(o[1]), w3 = bf16_hi(o[1]),
+                                        w4 = bf16_lo(o[2]), w5 = bf16_hi(o[2]), w6 = bf16_lo(o[3]), w7 = bf16_hi(o[3]);
+                            float s1 = ((w0 + w1) + (w2 + w3)) + ((w4 + w5) + (w6 + w7));
+                            float s2 = w0 * w0;
+                            s2 = __builtin_fmaf(w1, w1, s2);
+                            s2 = __builtin_fmaf(w2, w2, s2);
+                            s2 = __builtin_fmaf(w3, w3, s2);
+                            s2 = __builtin_fmaf(w4, w4, s2);
+                            s2 = __builtin_fmaf(w5, w5, s2);
+                            s2 = __builtin_fmaf(w6, w6, s2);
+                            s2 = __builtin_fmaf(w7, w7, s2);
                             s1 = sum8_dpp(s1);
                             s2 = sum8_dpp(s2);
                             if (c8 == 0 && m < p.M) {
@@ -489,14 +500,8 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
                                 *reinterpret_cast<f32x2s*>(p.row_part + ((int64_t)m * (p.N >> 6) + (nw >> 6)) * 2) = f32x2s{s1, s2};
                             }
                         }
-                        if (m < p.M && n < p.N) {
-                            u32x4 o;
-                            o[0] = pack_bf16x2(v0, v1);
-                            o[1] = pack_bf16x2(v2, v3);
-                            o[2] = pack_bf16x2(v4, v5);
-                            o[3] = pack_bf16x2(v6, v7);
+                        if (m < p.M && n < p.N)
                             *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(p.C) + p.c.off(m) + n) = o;
-                        }
                     }
                 }
                 return;

@@ -99,6 +99,33 @@ def all_reduce_flat(grad: torch.Tensor, average: bool = True, bucket_bytes: int 
     return grad
 
 
+def used_anywhere(used: List[bool], device) -> List[bool]:
+    """Element-wise OR over the ranks of a per-parameter 'has a gradient' list.  A parameter no rank used keeps
+    grad None everywhere (what DDP's find_unused_parameters bookkeeping does, tasks/shared_utils.py:54-59); one used
+    on any rank must get the reduced gradient on every rank, or the replicas drift apart."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return list(used)
+    flags = torch.tensor([1 if u else 0 for u in used], dtype=torch.int32, device=device)
+    dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+    return [bool(f) for f in flags.tolist()]
+
+
+def reduce_param_grads(arena, average: bool = True, bucket_bytes: int = 64 << 20):
+    """Blocking data-parallel exchange for the autograd route: `arena` is a hawkeye_amd.train.ParamArena.  Gradients
+    that live outside the arena (autograd cloned or accumulated them) are copied in and `p.grad` is rebound to the
+    arena view, parameters without a gradient on this rank but with one elsewhere contribute zeros and receive the
+    result, the flat arena is all-reduced, and every rank ends with identical `p.grad`s."""
+    used = used_anywhere([p.requires_grad and p.grad is not None for p in arena.params], arena.grad.device)
+    used = [u and p.requires_grad for u, p in zip(used, arena.params)]
+    arena.bind_grads({n for n, u in zip(arena.names, used) if u})
+    with torch.no_grad():
+        for n, p, u in zip(arena.names, arena.params, used):
+            if not u and p.requires_grad:
+                arena.grad_view(n, p).zero_()        # unused everywhere: nothing to add, p.grad stays None
+    all_reduce_flat(arena.grad, average=average, bucket_bytes=bucket_bytes)
+    return used
+
+
 class BucketReducer:
     """Overlaps the gradient all-reduce with the backward.  QFormerTrainEngine.backward calls ready(n) when arena
     elements [0, n) are final; every whole bucket below n that has not been sent yet is all-reduced on a side
@@ -108,10 +135,11 @@ class BucketReducer:
     Bucket size: xGMI is point-to-point, a ring all-reduce is bound by one ~153 GB/s link, so buckets are large
     (default 64 MB: ~1 ms on the wire at 8 GPUs) -- a dozen collectives per step instead of DDP's 25 MB default."""
 
-    def __init__(self, grad: torch.Tensor, average: bool = True, bucket_bytes: int = 64 << 20):
+    def __init__(self, grad: torch.Tensor, average: bool = True, bucket_bytes: int = 64 << 20, force: bool = False):
+        """force: run the collectives even in a one-rank group (tests: the overlapped path on one GPU)."""
         self.grad, self.average = grad, average
         self.bounds = bucket_bounds(grad.numel(), bucket_bytes // grad.element_size())
-        self.active = dist.is_initialized() and dist.get_world_size() > 1
+        self.active = dist.is_initialized() and (dist.get_world_size() > 1 or force)
         self.cuda = grad.is_cuda
         self.stream = torch.cuda.Stream(device=grad.device) if (self.cuda and self.active) else None
         self.sent = 0

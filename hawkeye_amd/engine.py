@@ -20,6 +20,7 @@ Data layout in HBM (row-major, M = B*N image tokens, N = T*L):
 import ctypes as C
 import math
 import os
+from collections import OrderedDict
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -31,14 +32,47 @@ from .config import EncoderConfig
 LOG2E = 1.4426950408889634
 
 
+class _Pool:
+    """Grow-only device buffers shared by every plan of an engine.
+
+    A plan's workspace tensors are views of these buffers, so the memory an engine holds is the largest size each
+    buffer was ever asked for -- not the sum over every (B, T, Lt) it has seen (instruction length varies per batch
+    with padding='longest', hawkeye_it.py:243-249: a real eval or training run meets tens of shapes).  Plans run one
+    after another on a stream, so sharing is safe under the same rule as before: one call in flight per engine.
+    When a buffer has to grow, the plans built earlier hold descriptors into the old allocation: `epoch` moves and
+    the owner drops them."""
+
+    def __init__(self, device):
+        self.device = device
+        self.bufs: Dict[str, torch.Tensor] = {}
+        self.epoch = 0
+
+    def view(self, name, shape, dtype) -> torch.Tensor:
+        n = math.prod(shape) * torch.empty((), dtype=dtype).element_size()
+        t = self.bufs.get(name)
+        if t is None or t.numel() < n:
+            if t is not None:
+                self.epoch += 1
+                self.bufs[name] = t = None      # release before the larger allocation
+            t = torch.empty((n + 255) // 256 * 256, dtype=torch.uint8, device=self.device)
+            self.bufs[name] = t
+        return t[:n].view(dtype).view(shape)
+
+    def nbytes(self) -> int:
+        return sum(t.numel() for t in self.bufs.values())
+
+
 class _Plan:
-    def __init__(self):
+    def __init__(self, pool: Optional[_Pool] = None):
+        self.pool = pool
+        self.pool_epoch = pool.epoch if pool is not None else 0
         self.ws: Dict[str, torch.Tensor] = {}
         self.steps: List[Tuple] = []       # (fn, args) ; stream appended at run time
         self.keep: List = []               # descriptors / ctypes objects kept alive
         self.patch_desc: Optional[L.HkGemmDesc] = None
         self.vit_end = 0                   # steps[:vit_end] = the ViT up to vision_layernorm (what training reuses)
-        self.graphs: Dict[Tuple, "torch.cuda.CUDAGraph"] = {}   # captured calls, keyed by (input kind, table, norm)
+        # captured calls, keyed by (input kind, table address, norm) -> (graph, the table it reads: kept alive with it)
+        self.graphs: "OrderedDict[Tuple, Tuple]" = OrderedDict()
         # Q-Former text-branch FFN of each layer, free to run beside the query branch on a second stream:
         # (fork, start, end) step indices -- the fork point is right after the self-attention LayerNorm, steps
         # [start, end) are the branch, the main stream joins before step `end`
@@ -46,9 +80,12 @@ class _Plan:
         self.side_events: List = []
 
     def buf(self, name, shape, dtype, device):
-        t = torch.empty(shape, dtype=dtype, device=device)
+        t = self.pool.view(name, shape, dtype) if self.pool is not None else torch.empty(shape, dtype=dtype, device=device)
         self.ws[name] = t
         return t
+
+
+MAX_PLANS = 64      # host-side descriptor sets kept per engine (LRU); device memory is pooled, not per plan
 
 
 class HipEncoderEngine:
@@ -68,7 +105,9 @@ class HipEncoderEngine:
                 cfg.encoder_embed_dim // cfg.encoder_num_heads != 64 or cfg.qf_hidden // cfg.qf_heads != 64:
             raise RuntimeError("the HIP attention kernel is specialised for head size 64")
         self.w: Dict[str, torch.Tensor] = {}
-        self.plans: Dict[Tuple[int, int, int], _Plan] = {}
+        self.plans: "OrderedDict[Tuple[int, int, int], _Plan]" = OrderedDict()
+        self.pool = _Pool(self.device)
+        self.calls = 0          # every call that writes the pooled workspace counts (the training path's in-flight guard)
         self.n_cross = len([i for i in range(cfg.qf_layers) if i % cfg.cross_attention_freq == 0])
         self._tag = ""          # label of the plan steps being appended (profile() groups by it)
         # Optional hipGraph replay of a whole call for small sizes (HK_GRAPH=1, limit HK_GRAPH_MAX_FRAMES).  Off by
@@ -206,7 +245,7 @@ class HipEncoderEngine:
 
     def _build_plan(self, B: int, T: int, Lt: int) -> _Plan:
         cfg, dev, w = self.cfg, self.device, self.w
-        plan = _Plan()
+        plan = _Plan(self.pool)
         D, Hv = cfg.encoder_embed_dim, cfg.encoder_num_heads
         Lp = cfg.patches_per_frame
         N = T * Lp
@@ -389,17 +428,16 @@ class HipEncoderEngine:
                     plan.buf(name, tuple(image.shape), image.dtype, self.device)
                 ws[name].copy_(image, non_blocking=True)
                 gkey = (name, pos_embed.data_ptr(), norm)
-                g = plan.graphs.get(gkey)
+                g = plan.graphs.get(gkey, (None, None))[0]
                 if g is None:
                     self._enqueue(plan, ws[name], u8, norm, pos_embed, B, T, Lt, H, W, None)
                     torch.cuda.current_stream().synchronize()
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
                         self._enqueue(plan, ws[name], u8, norm, pos_embed, B, T, Lt, H, W, None)
-                    if len(plan.graphs) >= 4:      # e.g. a caller that assigns a fresh pos_embed tensor per call
-                        plan.graphs.pop(next(iter(plan.graphs)))
-                    plan.graphs[gkey] = g
-                    plan.keep.append(pos_embed)    # the captured launches read this table's address
+                    while len(plan.graphs) >= 4:   # e.g. a caller that assigns a fresh pos_embed tensor per call
+                        plan.graphs.popitem(last=False)
+                    plan.graphs[gkey] = (g, pos_embed)   # the captured launches read this table's address
                 g.replay()
             else:
                 self._enqueue(plan, image, u8, norm, pos_embed, B, T, Lt, H, W, profile)
@@ -442,16 +480,32 @@ class HipEncoderEngine:
         if pos_embed.shape[-2:] != (N, cfg.encoder_embed_dim) or pos_embed.dtype != torch.float32 or \
                 pos_embed.device != self.device or not pos_embed.is_contiguous():
             raise RuntimeError(f"pos_embed must be a contiguous fp32 [{N},{cfg.encoder_embed_dim}] tensor on {self.device}")
-        key = (B, T, Lt)
-        plan = self.plans.get(key)
-        if plan is None:
-            plan = self._build_plan(B, T, Lt)
-            self.plans[key] = plan
+        plan = self.plan_for(B, T, Lt)
+        self.calls += 1
         with torch.cuda.device(self.device):
             if Lt > 0:
                 plan.ws["ids"].copy_(input_ids, non_blocking=True)
                 plan.ws["mask"].copy_(text_mask, non_blocking=True)
         return plan, image, u8, B, T, Lt, H, W
+
+    def plan_for(self, B: int, T: int, Lt: int) -> _Plan:
+        """The plan of a shape: cached (LRU, MAX_PLANS descriptor sets), rebuilt when the pooled workspace moved."""
+        key = (B, T, Lt)
+        plan = self.plans.get(key)
+        if plan is not None and plan.pool_epoch == self.pool.epoch:
+            self.plans.move_to_end(key)
+            return plan
+        if plan is not None:
+            del self.plans[key]
+        epoch = self.pool.epoch
+        plan = self._build_plan(B, T, Lt)
+        if self.pool.epoch != epoch:
+            self.plans.clear()              # a buffer grew: every older plan points into the released allocation
+        plan.pool_epoch = self.pool.epoch
+        self.plans[key] = plan
+        while len(self.plans) > MAX_PLANS:
+            self.plans.popitem(last=False)
+        return plan
 
     def _enqueue(self, plan, image, u8, norm, pos_embed, B, T, Lt, H, W, profile, upto=None):
         """Every launch of one call, in order, on torch's current stream (also the body of the captured graph)."""
@@ -524,8 +578,13 @@ class HipEncoderEngine:
         return {t: (len(v) // reps, sum(v) / len(v)) for t, v in acc.items()}
 
     def workspace_bytes(self, B: int, T: int, Lt: int) -> int:
+        """Bytes of the pooled workspace the plan of this shape uses (0 if it was never built)."""
         plan = self.plans.get((B, T, Lt))
         return 0 if plan is None else sum(t.numel() * t.element_size() for t in plan.ws.values())
+
+    def pooled_bytes(self) -> int:
+        """Device memory the engine holds for workspace, whatever the number of shapes it has seen."""
+        return self.pool.nbytes()
 
 
 def flops_per_clip(cfg: EncoderConfig, T: int, Lt: int) -> float:

@@ -71,7 +71,7 @@ class LlamaPrefill:
             raise RuntimeError("hidden_size must be a multiple of 256 and intermediate_size of 64")
         self.lib = L.load()
         self.w: Dict[str, torch.Tensor] = {}
-        self.plans: Dict[Tuple[int, int, bool, bool], _Plan] = {}
+        self.plans: Dict[Tuple[int, int, bool, bool], _Plan] = {}   # (B, S, masked, explicit position ids)
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, sd: Dict[str, torch.Tensor], lora_alpha: float = 32.0):
@@ -138,7 +138,7 @@ class LlamaPrefill:
         plan.keep.append(d)
         plan.steps.append((self.lib.hk_gemm_bf16, (C.byref(d),), "hk_gemm_bf16"))
 
-    def _build_plan(self, B: int, S: int, masked: bool) -> _Plan:
+    def _build_plan(self, B: int, S: int, masked: bool, with_pos: bool = False) -> _Plan:
         cfg, dev, w = self.cfg, self.device, self.w
         D, I, H, hd, Lyr, V = (cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.head_dim,
                                cfg.num_hidden_layers, cfg.vocab_size)
@@ -157,6 +157,7 @@ class LlamaPrefill:
             ws["gu"] = torch.empty((M, 2 * I), dtype=bf16, device=dev)
             ws["act"] = torch.empty((M, I), dtype=bf16, device=dev)
             ws["last"] = torch.empty((B,), dtype=torch.int64, device=dev)
+            ws["pos"] = torch.empty((M,), dtype=torch.int32, device=dev) if with_pos else None
             ws["hl_f"] = torch.empty((B, D), dtype=f32, device=dev)
             ws["hl_b"] = torch.empty((B, D), dtype=bf16, device=dev)
             ws["logits"] = torch.empty((B, V), dtype=f32, device=dev)
@@ -170,7 +171,7 @@ class LlamaPrefill:
             plan.steps.append((self.lib.hk_rmsnorm, (P(x), L.HK_DT_F32, P(w[o + "n1"]), P(xn), M, D, cfg.rms_norm_eps),
                                "hk_rmsnorm"))
             self._gemm(plan, P(xn), w[o + "qkv"], P(qkv), M, 3 * D, D)
-            plan.steps.append((self.lib.hk_rope_bf16, (P(qkv), P(w["cos"]), P(w["sin"]), None, M, H, hd, S,
+            plan.steps.append((self.lib.hk_rope_bf16, (P(qkv), P(w["cos"]), P(w["sin"]), P(ws["pos"]) if with_pos else None, M, H, hd, S,
                                                        cfg.max_position_embeddings, qscale), "hk_rope_bf16"))
             ad = ops.attn_desc(P(qkv), P(qkv) + D * eb, P(qkv) + 2 * D * eb, P(att), B, H, S, S,
                                3 * D, 3 * D, 3 * D, D, S * 3 * D, S * 3 * D, S * 3 * D, S * D,
@@ -194,10 +195,17 @@ class LlamaPrefill:
     # ------------------------------------------------------------------ run
     @torch.no_grad()
     def prefill(self, src: Optional[torch.Tensor] = None, video: Optional[torch.Tensor] = None,
-                inputs_embeds: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None):
+                inputs_embeds: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
+                position_ids=None):
         """Either `src` int64 [B,S] (token id >= 0, or -(video row)-1 for a spliced video token) with `video`
         [B*n, D] bf16/fp32 (encode_img's output), or ready `inputs_embeds` [B,S,D].  attention_mask [B,S] (1 =
-        token, 0 = right/left padding) or None.  Returns {"hidden": bf16 [B,S,D] after the final RMSNorm,
+        token, 0 = padding on either side) or None; logits are read at the LAST 1 of every row.
+        position_ids: None = 0..S-1 for every row, what LlamaModel.forward does when none are passed
+        (modeling_llama.py:526-533: the training forward, hawkeye_it.py:369-375, right padding); "generate" = the ids
+        `generate` builds for a (left-)padded batch, cumsum(mask) - 1 with padded positions at 1
+        (prepare_inputs_for_generation :751-754); or an explicit integer tensor [B,S].  A left-padded mask with the
+        default ids is refused: the reference never runs that combination and its positions would be shifted.
+        Returns {"hidden": bf16 [B,S,D] after the final RMSNorm,
         "logits": fp32 [B,V] at each row's last valid position, "kv": [(k, v)] per layer as [B,S,H,hd] bf16 views
         (k post-rotary), valid until the next call with the same (B, S)}.  Padded positions hold unspecified values."""
         cfg = self.cfg
@@ -212,10 +220,16 @@ class LlamaPrefill:
         if ref.device != self.device:
             raise RuntimeError(f"inputs are on {ref.device}, model on {self.device}")
         masked = attention_mask is not None
-        key = (B, S, masked)
+        with_pos = position_ids is not None
+        if isinstance(position_ids, str):
+            if position_ids != "generate" or not masked:
+                raise RuntimeError('position_ids must be None, "generate" (needs attention_mask) or an int tensor [B,S]')
+        elif with_pos and (tuple(position_ids.shape) != (B, S) or position_ids.device != self.device):
+            raise RuntimeError(f"position_ids must be an integer tensor [{B},{S}] on {self.device}")
+        key = (B, S, masked, with_pos)
         plan = self.plans.get(key)
         if plan is None:
-            plan = self._build_plan(B, S, masked)
+            plan = self._build_plan(B, S, masked, with_pos)
             self.plans[key] = plan
         ws = plan.ws
         D, H, hd = cfg.hidden_size, cfg.num_attention_heads, cfg.head_dim
@@ -227,11 +241,28 @@ class LlamaPrefill:
                 ws["mask"].copy_(attention_mask, non_blocking=True)
                 L.check(self.lib.hk_qformer_key_bias(ws["mask"].data_ptr(), ws["kbias"].data_ptr(), B, 0, S, stream),
                         "hk_qformer_key_bias")
-                # index of the last valid token per row (data movement only: a sum over a [B,S] int mask)
-                last = ws["mask"].sum(1) - 1 + torch.arange(B, device=self.device) * S
-                ws["last"].copy_(last.clamp_min(0))
+                # index of the last valid token per row = position of the last 1 (right OR left padding); index
+                # bookkeeping over a [B,S] int mask, like the reference's own cumsum
+                m = ws["mask"]
+                if not with_pos and bool((m[:, 0] == 0).any()):
+                    raise RuntimeError('prefill: the mask is left-padded; pass position_ids="generate" (what generate() '
+                                       "uses, modeling_llama.py:751-754) or explicit position_ids")
+                last = S - 1 - m.flip(1).argmax(1) + torch.arange(B, device=self.device) * S
+                ws["last"].copy_(last)
+                if with_pos:
+                    if isinstance(position_ids, str):
+                        pos = (m.cumsum(1) - 1).masked_fill_(m == 0, 1)
+                    else:
+                        pos = position_ids
+                    if int(pos.min()) < 0 or int(pos.max()) >= cfg.max_position_embeddings:
+                        raise RuntimeError("position_ids outside [0, max_position_embeddings)")
+                    ws["pos"].copy_(pos.reshape(-1))
             else:
                 ws["last"].copy_(torch.arange(B, device=self.device) * S + (S - 1))
+                if with_pos:
+                    if int(position_ids.min()) < 0 or int(position_ids.max()) >= cfg.max_position_embeddings:
+                        raise RuntimeError("position_ids outside [0, max_position_embeddings)")
+                    ws["pos"].copy_(position_ids.reshape(-1))
             if src is not None:
                 ws["src"].copy_(src.reshape(-1), non_blocking=True)
                 vid = None

@@ -182,24 +182,38 @@ def disabled_train(self, mode=True):   # blip2.py:90-93
 class _EncodeImgFn(torch.autograd.Function):
     """encode_img as one autograd node (row f2): forward = the HIP training forward, backward = the HIP backward.
     The trainable parameters are inputs of the node, so autograd (and DistributedDataParallel's hooks,
-    tasks/shared_utils.py:54-59) see real gradients for real nn.Parameters."""
+    tasks/shared_utils.py:54-59) see real gradients for real nn.Parameters.
+
+    The gradients the node returns are VIEWS of the engine's flat gradient arena (no 741 MB copy per step).  Autograd
+    either adopts such a view as `p.grad` or adds it into an existing `p.grad`; the arena is overwritten by the next
+    backward, so a `p.grad` that still aliases it when the next backward starts (gradient accumulation,
+    zero_grad(set_to_none=False)) is moved to a tensor of its own first."""
 
     @staticmethod
     def forward(ctx, model, image, ids, mask, table, norm, train, seed, *params):
         eng = model._train_engine
         out, plan = eng.forward(image, ids, mask, table, train=train, seed=seed, norm=norm)
-        ctx.model, ctx.plan, ctx.generation = model, plan, plan.generation
+        ctx.model, ctx.plan, ctx.engine, ctx.stamp = model, plan, eng, plan.stamp
         return out.clone()
 
     @staticmethod
     def backward(ctx, dout):
-        eng, plan = ctx.model._train_engine, ctx.plan
-        if plan.generation != ctx.generation:
-            raise RuntimeError("encode_img was called again with the same input shape before backward(): the saved "
-                               "activations of this call are gone (one in-flight training call per shape)")
-        eng.backward(plan, dout)
+        eng, plan, model = ctx.engine, ctx.plan, ctx.model
+        if eng is not model._train_engine:
+            raise RuntimeError("the training engine was rebuilt between forward and backward()")
+        eng.check_in_flight(plan, ctx.stamp)
         ar = eng.arena
-        grads = tuple(ar.grad_view(n, p).clone() if p.requires_grad else None for n, p in zip(ar.names, ar.params))
+        with torch.no_grad():
+            for n, p in zip(ar.names, ar.params):
+                if ar.grad_aliases(n, p):
+                    p.grad = p.grad.clone()
+        reducer = model._grad_reducer()
+        eng.backward(plan, dout, reducer)
+        used = [p.requires_grad and n not in plan.unused for n, p in zip(ar.names, ar.params)]
+        if reducer is not None and reducer.active:
+            from . import dist as hdist
+            used = [u and p.requires_grad for u, p in zip(hdist.used_anywhere(used, ar.grad.device), ar.params)]
+        grads = tuple(ar.grad_view(n, p) if u else None for (n, p), u in zip(zip(ar.names, ar.params), used))
         return (None,) * 8 + grads
 
 
@@ -236,6 +250,8 @@ class HawkEyeEncoder(nn.Module):
         self._engine: Optional[HipEncoderEngine] = None
         self._engine_key = {"vit": None, "qformer": None}
         self._train_engine: Optional[QFormerTrainEngine] = None
+        self._overlap = None      # (average, bucket_mb) once enable_overlapped_grad_reduce() was called
+        self._reducer = None
         # Q-Former dropout (blip2.py:56-64; config.json:29-31).  Active iff self.qformer.training, like nn.Dropout.
         self.qformer_hidden_dropout_prob = 0.1
         self.qformer_attention_probs_dropout_prob = 0.1
@@ -341,15 +357,45 @@ class HawkEyeEncoder(nn.Module):
 
     def reset_train_engine(self):
         self._train_engine = None
+        self._reducer = None
+
+    # Data parallelism of the stage-3 step (tasks/shared_utils.py:54-59 wraps the model in DistributedDataParallel).
+    # Three routes, all ending with `p.grad` of every replica holding the same averaged gradient:
+    #   1. DistributedDataParallel(model, find_unused_parameters=True) as the reference does: the node's gradients reach
+    #      DDP's hooks like any other; nothing to call.
+    #   2. out.backward(); model.all_reduce_gradients(): blocking flat all-reduce of the gradient arena.
+    #   3. model.enable_overlapped_grad_reduce() once, then just out.backward(): the arena is all-reduced in buckets on a
+    #      side stream WHILE the backward is still producing earlier layers' gradients (hawkeye_amd/dist.py BucketReducer).
+    # Do not combine 1 with 2 / 3 (the gradients would be averaged twice).
+    def enable_overlapped_grad_reduce(self, average: bool = True, bucket_mb: int = 64, force: bool = False):
+        self._overlap = (bool(average), int(bucket_mb), bool(force))
+        self._reducer = None
+
+    def disable_overlapped_grad_reduce(self):
+        self._overlap = None
+        self._reducer = None
+
+    def _grad_reducer(self):
+        if self._overlap is None:
+            return None
+        te = self._train_engine
+        if self._reducer is None or self._reducer.grad is not te.arena.grad:
+            from . import dist as hdist
+            self._reducer = hdist.BucketReducer(te.arena.grad, average=self._overlap[0], bucket_bytes=self._overlap[1] << 20,
+                                                  force=self._overlap[2])
+        return self._reducer
 
     def all_reduce_gradients(self, average: bool = True, bucket_mb: int = 64):
-        """Data-parallel gradient exchange of the trainable parameters, straight on the flat gradient arena
-        (hawkeye_amd/dist.py); the alternative to wrapping the model in DistributedDataParallel."""
+        """Route 2: data-parallel gradient exchange of the trainable parameters on the flat gradient arena
+        (hawkeye_amd/dist.py reduce_param_grads); the alternative to wrapping the model in DistributedDataParallel.
+        Whatever autograd did with the node's gradients (adopted the arena views, cloned them, accumulated several
+        micro-batches), they are first made views of the arena again, so the reduced values ARE the `p.grad` the
+        optimizer reads."""
         from . import dist as hdist
         te = self._train_engine
         if te is None:
             raise RuntimeError("all_reduce_gradients: no training call has run yet")
-        hdist.all_reduce_flat(te.arena.grad, average=average, bucket_bytes=bucket_mb << 20)
+        hdist.reduce_param_grads(te.arena, average=average, bucket_bytes=bucket_mb << 20)
 
     def _table(self, use_image: bool, n_tokens: int, dev) -> torch.Tensor:
         enc = self.vision_encoder.encoder

@@ -25,7 +25,7 @@ import torch
 from . import lib as L
 from . import ops
 from .config import EncoderConfig
-from .engine import HipEncoderEngine, LOG2E
+from .engine import HipEncoderEngine, LOG2E, _Pool
 
 # dropout-site kinds inside one BertLayer (the oracle and the golden generator use the same numbering)
 SELF_PROB, SELF_HID, SELF_PATH, CROSS_PROB, CROSS_HID, CROSS_PATH, QFFN_HID, QFFN_PATH, TFFN_HID, TFFN_PATH = range(10)
@@ -93,7 +93,9 @@ class ParamArena:
         self.adopt()
 
     def adopt(self):
-        """Move every parameter's storage into the arena (values kept) and point .grad at the gradient arena."""
+        """Move every parameter's storage into the arena (values kept).  `.grad` is not touched here: gradients reach
+        the parameters as views of the gradient arena through the autograd node (model._EncodeImgFn) or through
+        bind_grads()."""
         with torch.no_grad():
             for n, p in zip(self.names, self.params):
                 o = self.offset[n]
@@ -113,6 +115,27 @@ class ParamArena:
         o = self.offset[n]
         return self.grad[o:o + p.numel()].view(p.shape)
 
+    def grad_aliases(self, n: str, p) -> bool:
+        """True if p.grad is the arena's own memory for this parameter (autograd adopted the returned view)."""
+        return p.grad is not None and p.grad.data_ptr() == self.g32(n) and p.grad.is_contiguous()
+
+    def bind_grads(self, names=None):
+        """Make `p.grad` the arena view of every parameter in `names` (default: every parameter that requires grad).
+        A gradient that lives elsewhere (autograd cloned it, or accumulated into its own tensor) is copied in first,
+        so afterwards the flat arena IS what the optimizer reads: the precondition of a flat all-reduce."""
+        with torch.no_grad():
+            for n, p in zip(self.names, self.params):
+                if not p.requires_grad or (names is not None and n not in names):
+                    continue
+                if self.grad_aliases(n, p):
+                    continue
+                view = self.grad_view(n, p)
+                if p.grad is None:
+                    view.zero_()
+                else:
+                    view.copy_(p.grad)
+                p.grad = view
+
     def p32(self, n: str) -> int:
         return self.flat.data_ptr() + 4 * self.offset[n]
 
@@ -124,7 +147,9 @@ class ParamArena:
 
 
 class _TrainPlan:
-    def __init__(self):
+    def __init__(self, pool: Optional[_Pool] = None):
+        self.pool = pool
+        self.pool_epoch = pool.epoch if pool is not None else 0
         self.ws: Dict[str, torch.Tensor] = {}
         self.fwd: List[Tuple] = []
         self.bwd: List[Tuple] = []
@@ -132,10 +157,11 @@ class _TrainPlan:
         self.drops: List[Tuple] = []      # (HkDropout, p, p_path)
         self.attns: List[Tuple] = []      # (HkAttnTrainDesc, p)
         self.marks: List[Tuple[int, int]] = []   # (index into bwd after which ..., gradient arena offset finished)
-        self.generation = 0
+        self.stamp: Optional[Tuple[int, int]] = None   # (inference-engine calls, training forwards) after this plan's forward
+        self.unused: frozenset = frozenset()     # trainable parameters this shape never touches (gradient None)
 
     def buf(self, name, shape, dtype, device):
-        t = torch.empty(shape, dtype=dtype, device=device)
+        t = self.pool.view(name, shape, dtype) if self.pool is not None else torch.empty(shape, dtype=dtype, device=device)
         self.ws[name] = t
         return t
 
@@ -159,6 +185,10 @@ class QFormerTrainEngine:
         self._pack_steps: List[Tuple] = []
         self._packed_version = None
         self.plans: Dict[Tuple[int, int, int], _TrainPlan] = {}
+        # saved activations and backward scratch of every shape share one grow-only pool, like the inference workspace
+        # (engine._Pool): one training call is in flight per engine, whatever its shape
+        self.pool = _Pool(self.device)
+        self.forwards = 0
         self._build_pack()
 
     # ------------------------------------------------------------------ weights
@@ -237,11 +267,8 @@ class QFormerTrainEngine:
 
     def _build_plan(self, B: int, T: int, Lt: int) -> _TrainPlan:
         cfg, dev, ar, lib = self.cfg, self.device, self.arena, self.lib
-        plan = _TrainPlan()
-        enc_plan = self.enc.plans.get((B, T, Lt))
-        if enc_plan is None:
-            enc_plan = self.enc._build_plan(B, T, Lt)
-            self.enc.plans[(B, T, Lt)] = enc_plan
+        plan = _TrainPlan(self.pool)
+        enc_plan = self.enc.plan_for(B, T, Lt)
         plan.enc_plan = enc_plan
         d, H, I, nq, D = cfg.qf_hidden, cfg.qf_heads, cfg.qf_intermediate, cfg.n_query, cfg.encoder_embed_dim
         Lyr = cfg.qf_layers
@@ -477,6 +504,17 @@ class QFormerTrainEngine:
         wgrad(P(dkvc), M, KVW, P(xn), None, D, kw0, kb0)
         plan.marks.append((len(Bw), ar.total))
         plan.sv = sv
+        if Lt == 0:
+            # qformer_text_input=False (hawkeye_it.py:261-267): the text FFNs and the word / position tables never enter
+            # the graph, their gradients are None in the reference.  (With Lt > 0 every trainable parameter gets a
+            # gradient there, the last layer's text FFN included -- zeros, since only [:, :96] is read:
+            # tests/golden/train_small.npz `unused` is empty.)
+            un = [e + "position_embeddings.weight", e + "word_embeddings.weight"]
+            for i in range(Lyr):
+                for blk, tail in (("output", ("dense.weight", "dense.bias", "LayerNorm.weight", "LayerNorm.bias")),
+                                  ("intermediate", ("dense.weight", "dense.bias"))):
+                    un += [lname(i, f"{blk}.{t_}") for t_ in tail]
+            plan.unused = frozenset(un)
         return plan
 
     # ------------------------------------------------------------------ run
@@ -500,27 +538,46 @@ class QFormerTrainEngine:
         B, T = int(image.shape[0]), int(image.shape[1])
         Lt = 0 if input_ids is None else int(input_ids.shape[1])
         key = (B, T, Lt)
+        enc_plan = self.enc.plan_for(B, T, Lt)
         plan = self.plans.get(key)
-        if plan is None:
+        if plan is None or plan.enc_plan is not enc_plan or plan.pool_epoch != self.pool.epoch:
+            # new shape, or the pooled buffers it points into moved (here or in the inference engine)
+            epoch = self.pool.epoch
             plan = self._build_plan(B, T, Lt)
+            if self.pool.epoch != epoch:
+                self.plans.clear()
+            plan.pool_epoch = self.pool.epoch
             self.plans[key] = plan
+            while len(self.plans) > 64:
+                self.plans.pop(next(iter(self.plans)))
         self.pack()
         with torch.cuda.device(self.device):
             # the frozen ViT: the inference plan's launches up to vision_layernorm (validation of the inputs included)
             if self.enc.forward_vit(image, input_ids, text_mask, pos_embed, norm=norm) is not plan.enc_plan:
-                raise RuntimeError("the inference engine rebuilt its plans (weights were re-allocated); "
-                                   "call model.reset_train_engine()")
+                raise RuntimeError("internal: the inference plan changed between lookup and launch")
             self._arm(plan, train, seed)
-            plan.generation += 1
             plan.train, plan.seed = train, seed
             self._run(plan.fwd, torch.cuda.current_stream().cuda_stream)
+        self.forwards += 1
+        plan.stamp = (self.enc.calls, self.forwards)
         return plan.ws["out"].view(B, cfg.n_query, cfg.llama_hidden), plan
+
+    def check_in_flight(self, plan: _TrainPlan, stamp=None):
+        """The backward reads activations the forward left in pooled buffers (its own and the inference engine's
+        image_embeds / cross K,V / key bias / ids): any encode_img call on this model since that forward -- training
+        or inference, any shape -- has overwritten them."""
+        stamp = plan.stamp if stamp is None else stamp      # a caller that kept the stamp of ITS forward passes it
+        if stamp != (self.enc.calls, self.forwards) or plan.pool_epoch != self.pool.epoch:
+            raise RuntimeError("encode_img was called again on this model between a training forward and its backward(): "
+                               "the saved activations of that forward are gone (one in-flight training call per model; "
+                               "run validation probes after backward, or on a second model instance)")
 
     @torch.no_grad()
     def backward(self, plan: _TrainPlan, dout: torch.Tensor, reducer=None):
         """Gradients of sum(out * dout) w.r.t. every trainable parameter -> the gradient arena (overwritten, not
         accumulated).  reducer: optional hawkeye_amd.dist.BucketReducer notified as arena ranges complete."""
         ar = self.arena
+        self.check_in_flight(plan)
         if dout.device != self.device or dout.numel() != plan.ws["out"].numel():
             raise RuntimeError("backward: dout must be a GPU tensor shaped like encode_img's output")
         dout = dout.reshape(plan.ws["out"].shape).to(torch.float32).contiguous()

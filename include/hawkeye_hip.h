@@ -79,7 +79,7 @@ typedef struct hk_gemm_desc {
     const float* col_c;     /* [N] fp32 */
     /* Optional output for the LayerNorm that FOLLOWS this GEMM (vit.py:126-127: proj / fc2 + residual, then norm2 /
      * the next block's norm1): row_part[m][g] = (sum, sum of squares) over columns 64 g .. 64 g + 63 of row m of C,
-     * taken on the fp32 values before the output rounding; hk_row_stats_finalize turns them into (mean, rstd).
+     * taken on the bf16 values as stored (the matrix the consumer reads); hk_row_stats_finalize turns them into (mean, rstd).
      * Needs N % 128 == 0 and the bf16 in-place residual epilogue; NULL when unused. */
     float* row_part;        /* [M][N / 64][2] fp32 */
 } hk_gemm_desc;

@@ -97,11 +97,25 @@ def embed_splice(sd, src, video):
     return torch.where((src >= 0)[..., None], tok, vid)
 
 
-def prefill(sd, cfg, inputs_embeds, attention_mask, stages=None):
+def generation_position_ids(attention_mask):
+    """prepare_inputs_for_generation (:751-754): positions count the valid tokens, padded positions get 1."""
+    pos = attention_mask.long().cumsum(-1) - 1
+    return pos.masked_fill(attention_mask == 0, 1)
+
+
+def last_valid_index(attention_mask):
+    """Index of the last 1 of every row (right padding: sum - 1; left padding: S - 1)."""
+    S = attention_mask.shape[1]
+    return S - 1 - attention_mask.long().flip(1).argmax(1)
+
+
+def prefill(sd, cfg, inputs_embeds, attention_mask, stages=None, position_ids=None):
     """LlamaModel.forward (:482-611) with inputs_embeds + LlamaForCausalLM's lm_head (:688-700).
+    position_ids None = the forward's default arange (:526-533); generate passes generation_position_ids(mask).
     Returns (final-norm hidden [B,S,D], logits at each row's last valid position [B,V], [(k, v)] per layer)."""
     B, S, D = inputs_embeds.shape
-    position_ids = torch.arange(S)[None].expand(B, S)                       # :526-533
+    if position_ids is None:
+        position_ids = torch.arange(S)[None].expand(B, S)                   # :526-533
     mask = decoder_mask(attention_mask, S)
     cos_h, sin_h = rotary_tables(D // cfg["num_attention_heads"], cfg["max_position_embeddings"], cfg["rope_base"])
     x = inputs_embeds.float()
@@ -111,6 +125,6 @@ def prefill(sd, cfg, inputs_embeds, attention_mask, stages=None):
         if stages is not None:
             stages[f"layer{i}"] = x
     x = rmsnorm(x, sd["model.norm.weight"], cfg["rms_norm_eps"])
-    last = attention_mask.long().sum(1) - 1
+    last = last_valid_index(attention_mask)
     logits = F.linear(x[torch.arange(B), last], sd["lm_head.weight"])
     return x, logits, kv

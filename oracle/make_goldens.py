@@ -21,6 +21,7 @@ all in memory, none touching the reference checkout:
      fixture's frames are generated at the final resolution.
 
 Usage:  python oracle/make_goldens.py            (writes tests/golden/)
+        python oracle/make_goldens.py llm_leftpad  (round 2: the left-padded prefill fixture)
         python oracle/make_goldens.py round2     (only full_T12_B2 + small_video_notext, added in round 2)
         python oracle/make_goldens.py train      (only the row f2 training fixture)
 """
@@ -321,6 +322,46 @@ def llm_goldens(outdir):
     print("wrote llm_small.npz", tuple(out.logits.shape))
 
 
+def llm_leftpad_goldens(outdir):
+    """Row f1, batched generation: a LEFT-padded batch as `generate` prefills it -- position ids from the reference's
+    own prepare_inputs_for_generation (modeling_llama.py:744-773: cumsum(mask) - 1, masked positions set to 1),
+    logits read at the last position of every row."""
+    from hawkeye_amd.config import SMALL_LLM
+    spec = importlib.util.spec_from_file_location("ref_modeling_llama",
+                                                  os.path.join(REF, "models", "blip2", "modeling_llama.py"))
+    ml = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ml)
+    cfg, seed, B, S, nv = SMALL_LLM, 5, 3, 96, 16
+    lc = ml.LlamaConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
+                        num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+                        max_position_embeddings=cfg.max_position_embeddings, rms_norm_eps=cfg.rms_norm_eps,
+                        hidden_act="silu")
+    lc.num_frame_tokens = 0
+    model = ml.LlamaForCausalLM(lc).eval()
+    sd = W.make_llm_state_dict(cfg, seed)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all("rotary_emb" in k for k in missing), (missing, unexpected)
+    src, _ = W.make_prompt(cfg, B, S, nv, seed, ragged=False)
+    mask = torch.ones(B, S, dtype=torch.int64)
+    for b, n_pad in enumerate((0, 7, 70)):                 # row 2: more than one 64-key tile of padding
+        mask[b, :n_pad] = 0
+        src[b] = torch.roll(src[b], n_pad)                 # keeps <s> + the video block inside the valid part
+        src[b, :n_pad] = 2
+    video = W._normal("video_tokens", seed, (B * nv, cfg.hidden_size), 0.05)
+    with torch.no_grad():
+        tok = model.model.embed_tokens_(src.clamp_min(0))
+        emb = torch.where((src >= 0)[..., None], tok, video[(-src - 1).clamp_min(0)])
+        inp = model.prepare_inputs_for_generation(None, attention_mask=mask, inputs_embeds=emb, use_cache=True)
+        pos = inp["position_ids"]
+        out = model(inputs_embeds=inp["inputs_embeds"], attention_mask=inp["attention_mask"], position_ids=pos,
+                    use_cache=True, output_hidden_states=True, return_dict=True)
+    rec = {"B": B, "S": S, "n_video": nv, "seed": seed, "src": src.numpy(), "mask": mask.numpy(), "video": video.numpy(),
+           "position_ids": pos.numpy(), "logits_last": out.logits[:, -1].numpy(),
+           "final_norm": out.hidden_states[-1].numpy(), "k0": out.past_key_values[0][0].numpy()}
+    np.savez_compressed(os.path.join(outdir, "llm_small_leftpad.npz"), **rec)
+    print("wrote llm_small_leftpad.npz", tuple(out.logits.shape), pos[:, :10].tolist())
+
+
 def _inject_masks(m, seed):
     """Train mode with reproducible randomness: every nn.Dropout / DropPath INSTANCE of the reference Q-Former gets a
     forward that applies the mask of oracle/dropout_masks.py for its site, so the reference's own module graph
@@ -419,6 +460,9 @@ def main():
         return
     if sys.argv[1:] == ["llm"]:
         llm_goldens(outdir)
+        return
+    if sys.argv[1:] == ["llm_leftpad"]:
+        llm_leftpad_goldens(outdir)
         return
     if sys.argv[1:] == ["train"]:
         ref_vit, ref_qf = _import_reference()

@@ -112,6 +112,60 @@ def test_two_rank_gloo_bucketed_gradient_all_reduce():
     assert all(ok for _, ok in res)
 
 
+def _param_grad_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from hawkeye_amd import dist as hd
+    from hawkeye_amd.train import ParamArena
+    hd.init("gloo")
+    torch.manual_seed(0)                                  # identical replicas
+    names = ["a", "b", "c", "d", "e"]
+    params = {n: torch.nn.Parameter(torch.randn(4, 8)) for n in names}
+    params["e"].requires_grad = False                     # a frozen tensor inside the arena
+    ar = ParamArena(params, names, "cpu")
+    ok = ar.attached()
+    g = {n: torch.full((4, 8), float(i + 1) * (rank + 1)) for i, n in enumerate(names)}
+    # what autograd can leave behind after the node returned arena views:
+    ar.grad_view("a").copy_(g["a"]); params["a"].grad = ar.grad_view("a")        # adopted the view
+    params["b"].grad = g["b"].clone()                                            # cloned / accumulated elsewhere
+    if rank == 0:
+        params["c"].grad = g["c"].clone()                                        # used on rank 0 only (e.g. Lt = 0 on rank 1)
+    ar.grad_view("d").fill_(123.0)                                               # unused everywhere: stale arena content
+    used = hd.reduce_param_grads(ar, average=True, bucket_bytes=4 * 48)
+    ok = ok and used == [True, True, True, False, False]
+    ok = ok and all(ar.grad_aliases(n, params[n]) for n in "abc") and params["d"].grad is None and params["e"].grad is None
+    ok = ok and torch.equal(params["a"].grad, torch.full((4, 8), 1.5)) and torch.equal(params["b"].grad, torch.full((4, 8), 3.0))
+    ok = ok and torch.equal(params["c"].grad, torch.full((4, 8), 1.5))           # (3 + 0) / 2 on BOTH ranks
+    # the optimizer reads p.grad: one SGD step must leave both replicas identical
+    opt = torch.optim.SGD([p for p in params.values() if p.requires_grad], lr=0.1)
+    opt.step()
+    flat = ar.flat.clone()
+    other = [torch.empty_like(flat) for _ in range(world)]
+    torch.distributed.all_gather(other, flat)
+    ok = ok and torch.equal(other[0], other[1]) and ar.attached()
+    hd.barrier()
+    q.put((rank, bool(ok)))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gloo_param_grads_end_identical_on_every_replica():
+    """The autograd route of row f2: whatever `p.grad` is after backward (arena view, separate tensor, None on one
+    rank), reduce_param_grads leaves every replica with the same averaged `p.grad` -- the tensors the optimizer
+    reads -- and keeps globally unused parameters at None (tasks/shared_utils.py:54-59 find_unused_parameters)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_param_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)
+
+
 def test_bucket_bounds_and_single_process_reducer():
     from hawkeye_amd import dist as hd
     assert hd.bucket_bounds(10, 4) == [(0, 4), (4, 8), (8, 10)]

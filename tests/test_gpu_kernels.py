@@ -165,8 +165,8 @@ def test_gemm_with_folded_layernorm(M, N, K, act):
 @pytest.mark.parametrize("M,N,K", [(512, 1024, 256), (100352 // 2 + 3, 1024, 1024), (300, 256, 128), (66000, 1024, 128)])
 def test_gemm_row_part_feeds_the_next_layernorm(M, N, K):
     """row_part of the in-place residual epilogue (persistent kernel, its split tail and the small kernel) ->
-    hk_row_stats_finalize == the statistics hk_row_stats takes from the stored bf16 rows, up to the bf16 rounding of
-    the rows themselves (the sums are taken before it)."""
+    hk_row_stats_finalize == the statistics hk_row_stats takes from the stored bf16 rows: the sums are taken from
+    the values as stored, so the mean the consuming GEMM subtracts is the mean of the matrix it multiplies."""
     x = _rand((M, K), 31, dtype=torch.bfloat16)
     w = _rand((N, K), 32, 0.05, dtype=torch.bfloat16)
     b = _rand((N,), 33)
@@ -178,14 +178,14 @@ def test_gemm_row_part_feeds_the_next_layernorm(M, N, K):
     plain = res.clone()
     ops.linear(x, w, b, residual=plain, out_dtype=torch.bfloat16, out=plain)
     assert torch.equal(out, plain)                      # the output itself is untouched by the extra sums
-    g = ref.view(M, N // 64, 64)
-    assert torch.allclose(part[:, :, 0], g.sum(2), rtol=1e-4, atol=1e-3)
-    assert torch.allclose(part[:, :, 1], (g * g).sum(2), rtol=1e-4, atol=1e-3)
+    assert (out.float() - ref).abs().max() <= 2 ** -8 * ref.abs().max()
+    g = out.float().view(M, N // 64, 64)                # the stored values, not the fp32 ones
+    assert torch.allclose(part[:, :, 0], g.sum(2), rtol=1e-5, atol=1e-4)
+    assert torch.allclose(part[:, :, 1], (g * g).sum(2), rtol=1e-5, atol=1e-4)
     st = ops.row_stats_finalize(part, 1e-6)
     st_ref = ops.row_stats(out, 1e-6)
-    # a stored element is off by up to 2^-9 |x| from the value that was summed; the mean of N of them by ~that / sqrt(N)
-    assert torch.allclose(st[:, 0], st_ref[:, 0], atol=4e-3 * float(ref.abs().max()) / math.sqrt(N))
-    assert torch.allclose(st[:, 1], st_ref[:, 1], rtol=2e-3)
+    assert torch.allclose(st[:, 0], st_ref[:, 0], atol=2e-6 * float(ref.abs().max()))
+    assert torch.allclose(st[:, 1], st_ref[:, 1], rtol=2e-5)
 
 
 def test_gemm_rejects_bad_shapes():

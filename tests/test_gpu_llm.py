@@ -169,6 +169,30 @@ def test_prefill_matches_reference_golden_and_oracle(golden_dir):
     assert prefill_flops(cfg, 1, 200) > 0
 
 
+def test_prefill_left_padded_batch_matches_reference_generate_prefill(golden_dir):
+    """A left-padded batch as `generate` prefills it (position ids cumsum(mask) - 1, logits at the last position):
+    against the reference-module fixture; the same mask with default position ids is refused."""
+    g = np.load(os.path.join(golden_dir, "llm_small_leftpad.npz"))
+    cfg, seed = SMALL_LLM, int(g["seed"])
+    m = LlamaPrefill(cfg, DEV).load_state_dict(W.make_llm_state_dict(cfg, seed))
+    src, mask = torch.from_numpy(g["src"]).to(DEV), torch.from_numpy(g["mask"]).to(DEV)
+    video = torch.from_numpy(g["video"]).to(DEV)
+    ref_l = torch.from_numpy(g["logits_last"]).to(DEV)
+    ref_h = torch.from_numpy(g["final_norm"]).to(DEV)
+    valid = mask.bool()
+    for pos in ("generate", torch.from_numpy(g["position_ids"]).to(DEV)):
+        out = m.prefill(src=src, video=video, attention_mask=mask, position_ids=pos)
+        assert _cos(out["logits"], ref_l) > 0.999 and _rel(out["logits"], ref_l) < 3e-2
+        for b in range(mask.shape[0]):          # row by row: a wrong last index / shifted positions shows per row
+            assert _cos(out["logits"][b], ref_l[b]) > 0.999, b
+        assert _cos(out["hidden"].float()[valid], ref_h[valid]) > 0.999
+        k0 = out["kv"][0][0]
+        rk = torch.from_numpy(g["k0"]).to(DEV).permute(0, 2, 1, 3)
+        assert _rel(k0.float()[valid], rk[valid]) < 1e-2
+    with pytest.raises(RuntimeError, match="left-padded"):
+        m.prefill(src=src, video=video, attention_mask=mask)
+
+
 def test_lora_merge_equals_adapter_forward():
     cfg, seed = SMALL_LLM, 4
     sd = W.make_llm_state_dict(cfg, seed)

@@ -219,7 +219,47 @@ def test_headline_shape_batch32_T16_clip_independence_and_oracle():
         assert c > 0.99999, (b, c)
     ref, _ = O.encode_img(sd, cfg.to_dict(), image[B - 1:].cpu(), ids[B - 1:], mask[B - 1:], table)
     _check("B32_T16.clip31 vs oracle", out[B - 1:], ref.numpy())
-    m._engine.plans.clear()        # 4.3 GB of workspace
+
+
+def test_workspace_is_pooled_across_instruction_lengths():
+    """padding='longest' (hawkeye_it.py:243-249) gives a different Lt per batch: 16 distinct Lt at the headline
+    shape must not grow the engine's memory (the workspace is pooled, not per plan), and a pooled plan gives the
+    same bits as a fresh engine that only ever saw that shape."""
+    cfg, seed, B, T = FULL, 29, 32, 16
+    m = _model(cfg, seed, T)
+    gen = torch.Generator(device=DEV).manual_seed(seed)
+    image = torch.randn(B, T, 3, cfg.img_size, cfg.img_size, generator=gen, device=DEV)
+    lts = list(range(32, 16, -1))
+    first = {}
+    base = None
+    for Lt in lts:
+        ids, mask = W.make_instruction_ids(B, Lt, cfg.qf_vocab, seed + Lt, ragged=True)
+        out, _ = m.encode_img(image, (ids, mask))
+        first[Lt] = out.clone()
+        torch.cuda.synchronize()
+        if base is None:
+            base = torch.cuda.memory_allocated()
+    grown = torch.cuda.memory_allocated() - base - sum(t.numel() * 4 for t in list(first.values())[1:])
+    print(f"[pool] memory growth over 16 instruction lengths: {grown / 2**20:.1f} MiB; pooled workspace "
+          f"{m._engine.pooled_bytes() / 2**30:.2f} GiB; plans {len(m._engine.plans)}")
+    assert grown < (1 << 30)
+    assert len(m._engine.plans) == len(lts)
+    # revisit a shape after the others used the same buffers: same bits
+    Lt = lts[3]
+    ids, mask = W.make_instruction_ids(B, Lt, cfg.qf_vocab, seed + Lt, ragged=True)
+    again, _ = m.encode_img(image, (ids, mask))
+    assert torch.equal(again, first[Lt])
+    # a growing sequence (smallest first) forces the pool to grow and plans to be rebuilt: still the same bits
+    del m
+    torch.cuda.empty_cache()
+    m2 = _model(cfg, seed, T)
+    ids0, mask0 = W.make_instruction_ids(2, 5, cfg.qf_vocab, seed, ragged=True)
+    m2.encode_img(image[:2], (ids0, mask0))
+    fresh, _ = m2.encode_img(image, (ids, mask))
+    assert torch.equal(fresh, first[Lt])
+    small_again, _ = m2.encode_img(image[:2], (ids0, mask0))     # its plan was dropped when the pool grew: rebuilt
+    assert torch.isfinite(small_again).all() and (2, T, 5) in m2._engine.plans
+    m2._engine.plans.clear()
 
 
 def test_fp32_residual_stream_mode(golden_dir):
@@ -308,6 +348,7 @@ def test_graph_replay_is_bit_identical_to_eager_launches():
         m.vision_encoder.encoder.pos_embed = posembed.video_pos_embed(
             2, cfg.patches_per_frame, cfg.encoder_embed_dim, cfg.ckpt_num_frame)
     assert eng.plans[(2, 2, 6)].graphs, "graph mode did not capture"
+    assert len(eng.plans[(2, 2, 6)].graphs) <= 4 and not any(torch.is_tensor(k) for k in eng.plans[(2, 2, 6)].keep)
     for a, b in zip(outs[False], outs[True]):
         assert torch.equal(a, b)
     assert not torch.equal(outs[True][0], outs[True][1])

@@ -139,6 +139,116 @@ def test_second_call_before_backward_is_reported(golden_dir):
         out1.sum().backward()
 
 
+def test_inference_call_between_forward_and_backward_is_reported(golden_dir):
+    """A validation probe (no_grad encode_img) overwrites image_embeds / cross K,V the backward reads: loud, not silent."""
+    g, cfg, sd, image, ids, mask, table, dout = load_case(golden_dir)
+    m = _model(cfg, sd, table, False)
+    args = (image.to(DEV), (ids.to(DEV), mask.to(DEV)))
+    out, _ = m.encode_img(*args)
+    with torch.no_grad():
+        m.encode_img(args[0][:1], (ids[:1].to(DEV), mask[:1].to(DEV)))      # another shape: the pool is shared
+    with pytest.raises(RuntimeError, match="saved activations"):
+        out.sum().backward()
+
+
+def test_gradients_are_arena_views_and_accumulate_like_autograd(golden_dir):
+    """The node hands out views of the flat gradient arena (no copy); a second backward without zero_grad adds to
+    the first like any autograd gradient; all_reduce_gradients leaves p.grad = the arena whatever happened before."""
+    g, cfg, sd, image, ids, mask, table, dout = load_case(golden_dir)
+    m = _model(cfg, sd, table, False)
+    args = (image.to(DEV), (ids.to(DEV), mask.to(DEV)))
+    d1, d2 = dout.to(DEV), torch.flip(dout, dims=(1,)).to(DEV) * 0.5
+    named = {n: p for n, p in m.named_parameters() if p.requires_grad}
+
+    def run(d):
+        out, _ = m.encode_img(*args)
+        (out * d).sum().backward()
+
+    run(d1)
+    ar = m._train_engine.arena
+    g1 = {n: p.grad.clone() for n, p in named.items()}
+    n_alias = sum(ar.grad_aliases(n, p) for n, p in zip(ar.names, ar.params))
+    print("gradients adopted as arena views:", n_alias, "of", len(ar.names))
+    for p in named.values():
+        p.grad = None
+    run(d2)
+    g2 = {n: p.grad.clone() for n, p in named.items()}
+    assert any(not torch.equal(g1[n], g2[n]) for n in named)
+    for p in named.values():
+        p.grad = None
+    run(d1)
+    run(d2)                                          # accumulation: no zero_grad in between
+    for n, p in named.items():
+        want = g1[n] + g2[n]
+        assert (p.grad - want).abs().max() <= 1e-6 * max(want.abs().max().item(), 1e-20), n
+    m.all_reduce_gradients()                         # one process: values unchanged, p.grad rebound to the arena
+    assert all(ar.grad_aliases(n, p) for n, p in zip(ar.names, ar.params) if p.requires_grad)
+    for n, p in named.items():
+        assert (p.grad - (g1[n] + g2[n])).abs().max() <= 1e-6 * max(g1[n].abs().max().item(), 1e-20), n
+
+
+def test_overlapped_bucket_reducer_from_the_autograd_node_equals_blocking_path(golden_dir):
+    """model.enable_overlapped_grad_reduce(): the BucketReducer runs inside encode_img's backward (RCCL on a side
+    stream, one-rank group here); p.grad equals the plain route bit for bit."""
+    import torch.distributed as tdist
+    g, cfg, sd, image, ids, mask, table, dout = load_case(golden_dir)
+    m = _model(cfg, sd, table, False)
+    args = (image.to(DEV), (ids.to(DEV), mask.to(DEV)))
+    named = {n: p for n, p in m.named_parameters() if p.requires_grad}
+    out, _ = m.encode_img(*args)
+    (out * dout.to(DEV)).sum().backward()
+    want = {n: p.grad.clone() for n, p in named.items()}
+    for p in named.values():
+        p.grad = None
+    from test_dist_cpu import _free_port
+    tdist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1,
+                             device_id=torch.device(DEV))
+    try:
+        m.enable_overlapped_grad_reduce(average=True, bucket_mb=1, force=True)
+        out, _ = m.encode_img(*args)
+        (out * dout.to(DEV)).sum().backward()
+        red = m._reducer
+        assert red is not None and red.active and len(red.log) >= 2, red.log      # several ranges, sent as they completed
+        assert red.log[0][0] == 0 and red.log[-1][1] == m._train_engine.arena.total
+        for n, p in named.items():
+            assert torch.equal(p.grad, want[n]), n
+    finally:
+        m.disable_overlapped_grad_reduce()
+        tdist.destroy_process_group()
+
+
+def test_no_text_training_leaves_text_parameters_without_gradient():
+    """qformer_text_input=False (hawkeye_it.py:261-267): the text FFNs and the word / position embeddings never enter
+    the graph -- their gradients are None, as in the reference, so AdamW leaves them alone."""
+    cfg, seed, B, T = SMALL_TRAIN, 4, 2, 2
+    sd = W.make_state_dict(cfg, seed)
+    table = posembed.video_pos_embed(T, cfg.patches_per_frame, cfg.encoder_embed_dim, cfg.ckpt_num_frame)
+    m = _model(cfg, sd, table, False)
+    m.qformer_text_input = False
+    image = W.make_clip(B, T, cfg.img_size, seed)
+    out, _ = m.encode_img(image.to(DEV), None)
+    out.square().mean().backward()
+    from oracle import encode_img_oracle as O
+    psd = {k: v.clone().requires_grad_(v.is_floating_point() and not k.startswith(("vision_encoder.", "vision_layernorm.")))
+           for k, v in sd.items()}
+    ref, _ = O.encode_img(psd, cfg.to_dict(), image, None, None, table)
+    ref.square().mean().backward()
+    text = ("intermediate.dense", "output.dense", "output.LayerNorm", "word_embeddings", "position_embeddings")
+    seen = 0
+    for n, p in m.named_parameters():
+        if not p.requires_grad:
+            continue
+        is_text = any(("." + t + ".") in ("." + n) for t in text) and "attention" not in n
+        assert (psd[n].grad is None) == is_text, n          # the oracle's autograd agrees on which ones are untouched
+        assert (p.grad is None) == is_text, n
+        if p.grad is not None and n.endswith("weight") and p.grad.abs().max() > 0:
+            r = psd[n].grad
+            cos = float((p.grad.double().flatten().cpu() @ r.double().flatten()) / (p.grad.double().norm().cpu() * r.double().norm()))
+            assert cos >= 0.995, (n, cos)
+            seen += 1
+    assert seen > 10
+
+
 def test_full_size_qformer_gradients_vs_oracle():
     """The shipped shapes of the Q-Former (768 wide, 12 layers, 12 heads, 6 cross layers, 96 queries), stage-3 batch
     of 2 clips (scripts/train/config_7b_stage3.py:15) at 2 frames so that the CPU oracle finishes in seconds."""

@@ -51,3 +51,24 @@ def test_padded_rows_do_not_influence_valid_rows():
         n = int(mask[1].sum())
         h2, l2, _ = LO.prefill(sd, cfg.to_dict(), emb[1:2, :n], mask[1:2, :n])
     assert torch.allclose(h1[1, :n], h2[0], atol=1e-5) and torch.allclose(l1[1], l2[0], atol=1e-5)
+
+
+def test_llm_oracle_left_padded_batch_with_generation_position_ids(golden_dir):
+    """Left padding as `generate` prefills it: position ids from the reference's prepare_inputs_for_generation
+    (modeling_llama.py:751-754), logits at the last position; fixture llm_small_leftpad.npz."""
+    g = np.load(os.path.join(golden_dir, "llm_small_leftpad.npz"))
+    cfg, seed = SMALL_LLM, int(g["seed"])
+    sd = W.make_llm_state_dict(cfg, seed)
+    src, mask = torch.from_numpy(g["src"]), torch.from_numpy(g["mask"])
+    pos = LO.generation_position_ids(mask)
+    assert np.array_equal(pos.numpy(), g["position_ids"])
+    assert LO.last_valid_index(mask).tolist() == [int(g["S"]) - 1] * int(g["B"])
+    assert LO.last_valid_index(torch.tensor([[1, 1, 0, 0], [0, 1, 1, 0]])).tolist() == [1, 2]
+    emb = LO.embed_splice(sd, src, torch.from_numpy(g["video"]))
+    with torch.no_grad():
+        hidden, logits, kv = LO.prefill(sd, cfg.to_dict(), emb, mask, position_ids=pos)
+    valid = mask.bool()
+    _close(hidden[valid], torch.from_numpy(g["final_norm"])[valid], "final_norm")
+    _close(logits, g["logits_last"], "logits_last")
+    vk = valid[:, None, :, None].expand_as(kv[0][0])
+    _close(kv[0][0][vk], torch.from_numpy(g["k0"])[vk], "k0")
