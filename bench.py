@@ -28,21 +28,47 @@ from hawkeye_amd.model import HawkEyeEncoder  # noqa: E402
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(sd, frames, lt, seed):
-    """The oracle (CPU fp32 restatement of the reference path) timed on this box's host cores,
-    one clip = a bounded sample of the same workload."""
+    """The oracle (CPU fp32 restatement of the reference path) timed on this box's host cores:
+    one clip at the headline frame count and one at Cfg1 (B=1, T=8), each 1 warm-up + 3 timed runs, median.
+    Threads: the box's CPU share for one GPU (OMP_NUM_THREADS there; os.cpu_count() where it is unset)."""
+    import statistics
     from oracle import encode_img_oracle as O
-    cores = int(os.environ.get("OMP_NUM_THREADS", 0)) or min(os.cpu_count() or 1, 16)
+    cores = int(os.environ.get("OMP_NUM_THREADS", 0)) or (os.cpu_count() or 1)
     torch.set_num_threads(cores)
-    image = W.make_clip(1, frames, FULL.img_size, seed)
-    ids, mask = W.make_instruction_ids(1, lt, FULL.qf_vocab, seed)
-    table = posembed.video_pos_embed(frames, FULL.patches_per_frame, FULL.encoder_embed_dim, FULL.ckpt_num_frame)
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        out, _ = O.encode_img(sd, FULL.to_dict(), image, ids, mask, table)
-    dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": f"1 clip, T={frames}, Lt={lt}, fp32 oracle (torch CPU, {cores} threads), {dt:.1f} s"}, out
+    model = _cpu_model()
+
+    def run(T, Lt_):
+        image = W.make_clip(1, T, FULL.img_size, seed)
+        ids, mask = W.make_instruction_ids(1, Lt_, FULL.qf_vocab, seed)
+        table = posembed.video_pos_embed(T, FULL.patches_per_frame, FULL.encoder_embed_dim, FULL.ckpt_num_frame)
+        times, out = [], None
+        for k in range(4):
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                out, _ = O.encode_img(sd, FULL.to_dict(), image, ids, mask, table)
+            if k > 0:
+                times.append(time.perf_counter() - t0)
+        return statistics.median(times), times, out
+
+    dt, times, out = run(frames, lt)
+    dt8, times8, _ = run(8, 12)
+    return {"value": round(1.0 / dt, 4), "unit": "clips/s", "cores": cores, "kind": "port", "cpu_model": model,
+            "logical_cpus_visible": os.cpu_count(),
+            "sample": f"1 clip, T={frames}, Lt={lt}, fp32 oracle (torch CPU, {cores} threads on {model}); 1 warm-up + 3 timed, "
+                      f"median {dt:.2f} s (runs {', '.join(f'{t:.2f}' for t in times)})",
+            "cfg1_B1_T8": {"value": round(1.0 / dt8, 4), "unit": "clips/s", "median_s": round(dt8, 3),
+                           "runs_s": [round(t, 3) for t in times8], "sample": "1 clip, T=8, Lt=12 (BASELINE configs[0])"}}, out
 
 
 def main():
@@ -127,18 +153,21 @@ def main():
         # the B clips one step processes / the step's device time from HIP events on the launch stream
         step_s = dev_ms / 1e3 / args.steps
         achieved = fl * B / step_s / 1e12
-        # HBM-side bytes per step from the committed rocprofv3 PMC passes (profiles/r01c_hbm_traffic.txt);
-        # PMC collection needs the profiler, so the live run quotes the profiled figure for this workload
+        # HBM-side bytes per step from the committed rocprofv3 PMC passes (profiles/rNN_hbm_traffic.txt -> traffic.json);
+        # PMC collection needs the profiler, so the live run quotes the profiled figure for this workload, and only
+        # while the kernel sources are the ones that were profiled (traffic.json carries their digest)
         tj = {}
         try:
+            from hawkeye_amd.lib import source_digest
             tj = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
-            if tj.get("workload") != f"B={B} T={T} Lt={Lt}":
+            # another workload, or counters taken with another kernel tree: no figure rather than a stale one
+            if tj.get("workload") != f"B={B} T={T} Lt={Lt}" or tj.get("csrc_digest") != source_digest():
                 tj = {}
         except (OSError, ValueError):
             tj = {}
         step_roof = {"kernel": "encode_img step (all launches of one call)", "achieved": round(achieved, 2),
                      "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                     "traffic": tj.get("bytes_per_step"), "gflop_per_clip": round(fl / 1e9, 1),
+                     "traffic": tj.get("bytes_per_step"), "traffic_source": tj.get("source"), "gflop_per_clip": round(fl / 1e9, 1),
                      "device_ms_per_step": round(step_s * 1e3, 3)}
         res = {
             "metric": "encode_img clips/s (UMT-L/16+QFormer,16f@224)", "value": round(value, 3), "unit": "clips/s",

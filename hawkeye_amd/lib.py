@@ -140,6 +140,20 @@ def load() -> C.CDLL:
     return lib
 
 
+def source_digest() -> str:
+    """sha1 over the kernel sources and the header the library is built from: profiles taken with another kernel
+    tree (profiles/traffic.json) are recognised as stale by it."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")))
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "hawkeye_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def last_error() -> str:
     buf = C.create_string_buffer(512)
     load().hk_last_error(buf, 512)

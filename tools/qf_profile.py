@@ -42,3 +42,17 @@ for t, (n, us) in sorted(prof.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
     if t.startswith("qf.") or t in ("llama_proj", "qformer.cross_kv"):
         print(f"{t:18s} x{n:3d}  {us:8.1f} us  total {n * us / 1e3:6.3f} ms  {n * us / tot * 100:5.1f} %")
 print(f"Q-Former side total {tot / 1e3:.3f} ms")
+allt = sum(n * us for n, us in prof.values())
+print(f"--- whole call: {len(plan.steps)} host launches, sum of launch durations {allt / 1e3:.3f} ms")
+for t, (n, us) in sorted(prof.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+    if not t.startswith("qf."):
+        print(f"{t:18s} x{n:3d}  {us:8.1f} us  total {n * us / 1e3:6.3f} ms  {n * us / allt * 100:5.1f} %")
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for _ in range(3):
+    model.encode_img(image, (ids, mask))
+e0.record()
+for _ in range(20):
+    model.encode_img(image, (ids, mask))
+e1.record()
+torch.cuda.synchronize()
+print(f"device time per call (no per-launch events): {e0.elapsed_time(e1) / 20:.3f} ms")

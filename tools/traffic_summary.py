@@ -3,7 +3,10 @@
 Counter values are KiB; FETCH_SIZE is doubled (gfx950 tallies its 128-byte read requests at 64 bytes:
 MI355X_MICROARCH.md, HBM / rocprofv3 section); these are fabric-side bytes, Infinity-Cache hits included.
 usage: traffic_summary.py <fetch_dir> <write_dir> <steps> <workload> <out.txt> <out.json>"""
-import collections, csv, glob, json, re, sys
+import collections, csv, glob, json, os, re, sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hawkeye_amd.lib import source_digest  # noqa: E402
 
 fdir, wdir, steps, workload, out_txt, out_json = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5], sys.argv[6]
 
@@ -39,6 +42,6 @@ lines.append(f"{'TOTAL':56s} {'':10s} {tf / 1e9:20.2f} {tw / 1e9:14.2f}")
 open(out_txt, "w").write("\n".join(lines) + "\n")
 per_kernel = {k: {"fetch_bytes_per_launch": 2 * fetch[k] / max(calls[k], 1), "write_bytes_per_launch": write.get(k, 0.0) / max(calls[k], 1),
                   "launches_per_step": calls[k] // steps} for k in fetch}
-json.dump({"bytes_per_step": tf + tw, "fetch_bytes": tf, "write_bytes": tw, "workload": workload, "source": out_txt.replace("gpurun_out/", "profiles/"),
+json.dump({"bytes_per_step": tf + tw, "fetch_bytes": tf, "write_bytes": tw, "workload": workload, "csrc_digest": source_digest(), "source": out_txt.replace("gpurun_out/", "profiles/"),
            "per_kernel": per_kernel}, open(out_json, "w"))
 print("\n".join(lines[-4:]))
