@@ -48,6 +48,10 @@ struct GemmParams {
     float scale;
     int nbm, nbn;
     int m_off;  // multi-stage kernel only: logical row of this launch's row 0 (tail launch of a split problem)
+    // multi-stage kernel only: split-K.  ksplit slices of kper K-tiles each; grid = tiles x ksplit; slice z writes its
+    // fp32 partial product to C + z * split_stride, slice 0 carries bias and residual
+    int ksplit, kper;
+    int64_t split_stride;
 };
 
 // Exact-erf GELU (nn.GELU default, vit.py:44; ACT2FN["gelu"], Qformer.py:383) to fp32 rounding noise:
@@ -645,9 +649,12 @@ __global__ __launch_bounds__(WM* WN * 64) void hk_gemm_kernel(const GemmParams p
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
 
-    const int lid = xcd_remap(blockIdx.x, p.nbm * p.nbn);
+    // split-K: consecutive workgroups are the slices of ONE tile (they share its A / W panels in time and in L2)
+    const int zs = p.ksplit > 1 ? (int)(blockIdx.x % (unsigned)p.ksplit) : 0;
+    const int lid = xcd_remap(p.ksplit > 1 ? (int)(blockIdx.x / (unsigned)p.ksplit) : (int)blockIdx.x, p.nbm * p.nbn);
     const int m0 = (lid / p.nbn) * BM;
     const int n0 = (lid % p.nbn) * BN;
+    const int kt0 = zs * p.kper;   // first K-tile of this slice
 
     // ---- loader state: each wave-instruction fills 8 rows x 128 B ----
     const int lrow = lane >> 3, lpc = lane & 7;
@@ -657,13 +664,13 @@ __global__ __launch_bounds__(WM* WN * 64) void hk_gemm_kernel(const GemmParams p
     for (int i = 0; i < A_IT; ++i) {
         const int row = (i * NW + wave) * 8 + lrow;
         const int m = min(m0 + row, p.M - 1);
-        aptr[i] = p.A + p.a.off(m + p.m_off) + ((lpc ^ ((row >> 1) & 7)) << 3);
+        aptr[i] = p.A + p.a.off(m + p.m_off) + ((lpc ^ ((row >> 1) & 7)) << 3) + kt0 * BK;
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
         const int row = (i * NW + wave) * 8 + lrow;
         const int n = min(n0 + row, p.N - 1);
-        bptr[i] = p.W + (int64_t)n * p.ldw + ((lpc ^ ((row >> 1) & 7)) << 3);
+        bptr[i] = p.W + (int64_t)n * p.ldw + ((lpc ^ ((row >> 1) & 7)) << 3) + kt0 * BK;
     }
     auto stage_load = [&](int stage, int kt) {
         __bf16* As = lds + stage * STAGE;
@@ -697,7 +704,7 @@ __global__ __launch_bounds__(WM* WN * 64) void hk_gemm_kernel(const GemmParams p
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int nc = min(ncol + j * 16, p.N - 4);
-        bias[j] = p.bias != nullptr ? *reinterpret_cast<const f32x4*>(p.bias + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bias[j] = (p.bias != nullptr && zs == 0) ? *reinterpret_cast<const f32x4*>(p.bias + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
         ccv[j] = p.row_stats != nullptr ? *reinterpret_cast<const f32x4*>(p.col_c + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
@@ -709,7 +716,9 @@ __global__ __launch_bounds__(WM* WN * 64) void hk_gemm_kernel(const GemmParams p
             meanv[i] = p.row_stats[2 * (int64_t)mc];
             rsv[i] = p.row_stats[2 * (int64_t)mc + 1];
         }
-        if (p.res) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) resraw[i][j] = u32x4{0u, 0u, 0u, 0u};
+        if (p.res && zs == 0) {
             const int64_t roff = p.r.off(mc);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
@@ -724,7 +733,7 @@ __global__ __launch_bounds__(WM* WN * 64) void hk_gemm_kernel(const GemmParams p
         }
     }
 
-    const int KT = p.K / BK;
+    const int KT = p.ksplit > 1 ? min(p.kper, p.K / BK - kt0) : p.K / BK;
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
         if (s < KT) stage_load(s, s);
@@ -762,7 +771,7 @@ __global__ __launch_bounds__(WM* WN * 64) void hk_gemm_kernel(const GemmParams p
     for (int i = 0; i < MI; ++i) {
         const int m = m0 + wm * TM + i * 16 + (lane & 15);
         if (m >= p.M) continue;
-        const int64_t coff = p.c.off(m + p.m_off);
+        const int64_t coff = p.c.off(m + p.m_off) + zs * p.split_stride;
         const float rs = rsv[i], rm = rsv[i] * meanv[i];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -811,7 +820,8 @@ int launch(const GemmParams& p, hipStream_t stream) {
     GemmParams q = p;
     q.nbm = (p.M + BM - 1) / BM;
     q.nbn = (p.N + BN - 1) / BN;
-    hipLaunchKernelGGL((hk_gemm_kernel<BM, BN, WM, WN, STAGES>), dim3(q.nbm * q.nbn), dim3(WM * WN * 64), LDS, stream, q);
+    hipLaunchKernelGGL((hk_gemm_kernel<BM, BN, WM, WN, STAGES>), dim3(q.nbm * q.nbn * (q.ksplit > 1 ? q.ksplit : 1)),
+                       dim3(WM * WN * 64), LDS, stream, q);
     HK_CHECK_LAUNCH("hk_gemm_bf16");
     return HK_OK;
 }
@@ -895,6 +905,13 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
                                           d->out_dtype == HK_DT_BF16 && (uintptr_t)d->row_part % 8 == 0),
                "hk_gemm_bf16: row_part needs N %% 128 == 0 and the bf16 residual-stream epilogue");
 
+    HK_REQUIRE(d->split_k <= 1 || (d->out_dtype == HK_DT_F32 && d->act == HK_ACT_NONE && d->row_stats == nullptr &&
+                                   d->row_part == nullptr && d->split_k <= d->K / 64 && d->split_k <= 64 &&
+                                   d->split_stride % 4 == 0 &&
+                                   (d->residual == nullptr || d->residual != d->C)),
+               "hk_gemm_bf16: split_k needs fp32 output, no activation / folded LayerNorm / row_part, split_k <= K / 64, "
+               "and a residual that is not the output buffer");
+
     GemmParams p;
     p.A = reinterpret_cast<const __bf16*>(d->A);
     p.W = reinterpret_cast<const __bf16*>(d->W);
@@ -918,6 +935,9 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
     p.scale = d->scale;
     p.nbm = p.nbn = 0;
     p.m_off = 0;
+    p.ksplit = 1;
+    p.kper = 0;
+    p.split_stride = 0;
     p.trace = nullptr;
     static const int dbg = getenv("HK_GEMM_DEBUG") ? atoi(getenv("HK_GEMM_DEBUG")) : 0;
     p.dbg = dbg;
@@ -937,15 +957,33 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
         if (t128 >= 128) return launch<128, 128, 2, 2, 4>(q, s);
         return launch<128, 64, 2, 2, 4>(q, s);
     };
-    // from half a chip's worth of 256x256 tiles up (one tile per CU, the rest idle) the ping-pong kernel still beats
-    // the multi-stage one: measured crossover ~128 tiles (prefill o_proj / down_proj at M = 2816: 42.1 -> 39.3 ms)
-    static const int pp_min = getenv("HK_GEMM_PP_MIN") ? atoi(getenv("HK_GEMM_PP_MIN")) : 128;
+    // from well under half a chip's worth of 256x256 tiles up (one tile per CU, the rest idle) the ping-pong kernel still
+    // beats the multi-stage one: prefill o_proj / down_proj at M = 2816, 176 tiles: 42.1 -> 39.3 ms; B = 1 qkv at
+    // M = 2352, 120 tiles: 36.3 -> 30.0 us (a B = 1, T = 12 call 5.88 -> 5.69 ms, same box); at 40 tiles (fc2, M = 2352)
+    // it loses badly (46 -> 81 us).  tools/small_gemm.py, HK_GEMM_PP_MIN=<tiles> to move the crossover.
+    static const int pp_min = getenv("HK_GEMM_PP_MIN") ? atoi(getenv("HK_GEMM_PP_MIN")) : 96;
     // the persistent kernel addresses its operand pieces as scalar base + 32-bit byte offset
     const int64_t a_last = d->a_rows.rows_per_batch == 0
                                ? (int64_t)(d->M - 1) * d->a_rows.ld
                                : (int64_t)((d->M - 1) / d->a_rows.rows_per_batch) * d->a_rows.batch_stride +
                                      (int64_t)((d->M - 1) % d->a_rows.rows_per_batch) * d->a_rows.ld;
     const bool off32 = (a_last + d->K) * 2 < (1LL << 32) && (int64_t)d->N * d->ldw * 2 < (1LL << 32);
+    if (d->split_k > 1) {
+        // few tiles, long K: slices of the K range on separate workgroups, partial products summed by the consumer
+        const int KT = d->K / 64;
+        p.kper = (KT + d->split_k - 1) / d->split_k;
+        p.ksplit = (KT + p.kper - 1) / p.kper;          // no empty slice
+        p.split_stride = d->split_stride;
+        if (p.ksplit < d->split_k) {
+            hk_set_error("hk_gemm_bf16: split_k=%d leaves empty slices for K=%d (use a divisor of K / 64 = %d)", d->split_k, d->K, KT);
+            return HK_EINVAL;
+        }
+        // kernel by the number of workgroups the slices make, like the unsplit choice below
+        const long t128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128) * p.ksplit;
+        if (t128 >= 384) return launch<128, 128, 2, 2, 2>(p, s);
+        if (t128 >= 128) return launch<128, 128, 2, 2, 4>(p, s);
+        return launch<128, 64, 2, 2, 4>(p, s);
+    }
     if (variant != 0 && tiles256 >= pp_min && d->N % 256 == 0 && off32) {
         // Tail balance: the persistent kernel gives each of the 256 CUs floor or ceil(tiles / 256) tiles, so a
         // last round that is less than half full (e.g. 1568 tiles = 6.125 rounds) idles most of the chip for a

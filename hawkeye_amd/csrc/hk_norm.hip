@@ -58,8 +58,8 @@ __device__ __forceinline__ void ln_finish(RowRegs<NCH>& x, int D, int lane, cons
 }
 
 template <int NCH, bool IN_BF16>
-__global__ __launch_bounds__(256) void hk_layernorm_kernel(const void* xin, const float* add, const float* gamma,
-                                                           const float* beta, __bf16* out_b, float* out_f,
+__global__ __launch_bounds__(256) void hk_layernorm_kernel(const void* xin, const float* add, int n_add, int64_t add_stride,
+                                                           const float* gamma, const float* beta, __bf16* out_b, float* out_f,
                                                            int64_t rows, int D, float eps, int64_t o_ld,
                                                            int64_t o_rpb, int64_t o_bs) {
     const int lane = threadIdx.x & 63;
@@ -76,7 +76,17 @@ __global__ __launch_bounds__(256) void hk_layernorm_kernel(const void* xin, cons
             } else {
                 x.v[c] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(xin) + row * D + i);
             }
-            if (add) x.v[c] += *reinterpret_cast<const f32x4*>(add + row * D + i);
+            // addends in index order: the sum of split-K partial products is the same bits on every run
+            // (four loads in flight at a time: a row of 96-row problems is one latency-bound chain otherwise)
+            for (int a = 0; a < n_add; a += 4) {
+                f32x4 t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    t[u] = a + u < n_add ? *reinterpret_cast<const f32x4*>(add + (a + u) * add_stride + row * D + i)
+                                         : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x.v[c] += t[u];
+            }
         }
     }
     int64_t oo = row * o_ld;
@@ -176,6 +186,61 @@ __global__ __launch_bounds__(256) void hk_row_stats_kernel(const __bf16* xin, fl
         }
     const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
     if (lane == 0) {
+        stats[2 * row] = mean;
+        stats[2 * row + 1] = rstd;
+    }
+}
+
+// Split-K tail of the proj / fc2 update of a SMALL call: x (bf16, in place) += sum of the fp32 slices (slice 0 carries
+// the bias), rounded once; (mean, rstd) of the stored row go to `stats` for the GEMM that consumes x with its
+// LayerNorm folded in.  Takes the place of hk_row_stats_finalize in the launch sequence.  Wave per row.
+template <int NCH8>
+__global__ __launch_bounds__(256) void hk_residual_add_parts_kernel(__bf16* x, const float* parts, int n_parts, int64_t stride,
+                                                                   float* stats, int64_t rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[NCH8][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH8; ++c) {
+        const int i = (c * 64 + lane) * 8;
+        if (i < D) {
+            const u32x4 w = *reinterpret_cast<const u32x4*>(x + row * D + i);
+            f32x4 a0 = f32x4{bf16_lo(w[0]), bf16_hi(w[0]), bf16_lo(w[1]), bf16_hi(w[1])};
+            f32x4 a1 = f32x4{bf16_lo(w[2]), bf16_hi(w[2]), bf16_lo(w[3]), bf16_hi(w[3])};
+            for (int a = 0; a < n_parts; ++a) {      // slices in index order: the same bits on every run
+                const float* pp = parts + a * stride + row * D + i;
+                a0 += *reinterpret_cast<const f32x4*>(pp);
+                a1 += *reinterpret_cast<const f32x4*>(pp + 4);
+            }
+            u32x4 o;
+            o[0] = pack_bf16x2(a0[0], a0[1]);
+            o[1] = pack_bf16x2(a0[2], a0[3]);
+            o[2] = pack_bf16x2(a1[0], a1[1]);
+            o[3] = pack_bf16x2(a1[2], a1[3]);
+            *reinterpret_cast<u32x4*>(x + row * D + i) = o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {            // statistics of the values as stored
+                v[c][2 * e] = bf16_lo(o[e]);
+                v[c][2 * e + 1] = bf16_hi(o[e]);
+                s += v[c][2 * e] + v[c][2 * e + 1];
+            }
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH8; ++c)
+        if ((c * 64 + lane) * 8 < D) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = v[c][e] - mean;
+                q += d * d;
+            }
+        }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    if (lane == 0 && stats) {
         stats[2 * row] = mean;
         stats[2 * row + 1] = rstd;
     }
@@ -282,21 +347,25 @@ __global__ __launch_bounds__(256) void hk_cast_kernel(const float* x, __bf16* ou
 }
 
 template <int NCH>
-void launch_ln(bool in_bf16, const void* x, const float* add, const float* gamma, const float* beta, __bf16* ob,
+void launch_ln(bool in_bf16, const void* x, const float* add, int n_add, int64_t add_stride, const float* gamma, const float* beta, __bf16* ob,
                float* of, int64_t rows, int D, float eps, hipStream_t s, int64_t o_ld, int64_t o_rpb, int64_t o_bs) {
     const dim3 grid((unsigned)((rows + 3) / 4));
     if (in_bf16)
-        hipLaunchKernelGGL((hk_layernorm_kernel<NCH, true>), grid, dim3(256), 0, s, x, add, gamma, beta, ob, of, rows, D, eps, o_ld, o_rpb, o_bs);
+        hipLaunchKernelGGL((hk_layernorm_kernel<NCH, true>), grid, dim3(256), 0, s, x, add, n_add, add_stride, gamma, beta, ob, of, rows, D, eps, o_ld, o_rpb, o_bs);
     else
-        hipLaunchKernelGGL((hk_layernorm_kernel<NCH, false>), grid, dim3(256), 0, s, x, add, gamma, beta, ob, of, rows, D, eps, o_ld, o_rpb, o_bs);
+        hipLaunchKernelGGL((hk_layernorm_kernel<NCH, false>), grid, dim3(256), 0, s, x, add, n_add, add_stride, gamma, beta, ob, of, rows, D, eps, o_ld, o_rpb, o_bs);
 }
 
 }  // namespace
 
-extern "C" int hk_layernorm(const void* x, int32_t in_dtype, const float* add, const float* gamma, const float* beta,
-                            void* out_bf16, float* out_f32, const hk_rows* out_rows, int64_t rows, int32_t D,
-                            float eps, void* stream) {
+extern "C" int hk_layernorm_parts(const void* x, int32_t in_dtype, const float* add, int32_t n_add, int64_t add_stride,
+                                  const float* gamma, const float* beta, void* out_bf16, float* out_f32,
+                                  const hk_rows* out_rows, int64_t rows, int32_t D, float eps, void* stream) {
     HK_REQUIRE(x && gamma && beta && (out_bf16 || out_f32), "hk_layernorm: null pointer");
+    HK_REQUIRE(n_add >= 0 && n_add <= 64 && (n_add == 0 || add != nullptr) && add_stride % 4 == 0 &&
+                   (n_add <= 1 || add_stride >= rows * (int64_t)D),
+               "hk_layernorm: bad addends (n_add=%d, stride=%ld)", n_add, (long)add_stride);
+    if (n_add == 0) add = nullptr;
     HK_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 4096, "hk_layernorm: bad shape rows=%ld D=%d", (long)rows, D);
     HK_REQUIRE(in_dtype == HK_DT_BF16 || in_dtype == HK_DT_F32, "hk_layernorm: unknown in_dtype %d", in_dtype);
     HK_REQUIRE(((uintptr_t)x | (uintptr_t)add | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)out_bf16 |
@@ -321,14 +390,20 @@ extern "C" int hk_layernorm(const void* x, int32_t in_dtype, const float* add, c
         return HK_OK;
     }
     const int nch = (D + 255) / 256;
-    if (nch <= 1) launch_ln<1>(ib, x, add, gamma, beta, ob, out_f32, rows, D, eps, s, o_ld, o_rpb, o_bs);
-    else if (nch <= 2) launch_ln<2>(ib, x, add, gamma, beta, ob, out_f32, rows, D, eps, s, o_ld, o_rpb, o_bs);
-    else if (nch <= 3) launch_ln<3>(ib, x, add, gamma, beta, ob, out_f32, rows, D, eps, s, o_ld, o_rpb, o_bs);
-    else if (nch <= 4) launch_ln<4>(ib, x, add, gamma, beta, ob, out_f32, rows, D, eps, s, o_ld, o_rpb, o_bs);
-    else if (nch <= 8) launch_ln<8>(ib, x, add, gamma, beta, ob, out_f32, rows, D, eps, s, o_ld, o_rpb, o_bs);
-    else launch_ln<16>(ib, x, add, gamma, beta, ob, out_f32, rows, D, eps, s, o_ld, o_rpb, o_bs);
+    if (nch <= 1) launch_ln<1>(ib, x, add, n_add, add_stride, gamma, beta, ob, out_f32, rows, D, eps, s, o_ld, o_rpb, o_bs);
+    else if (nch <= 2) launch_ln<2>(ib, x, add, n_add, add_stride, gamma, beta, ob, out_f32, rows, D, eps, s, o_ld, o_rpb, o_bs);
+    else if (nch <= 3) launch_ln<3>(ib, x, add, n_add, add_stride, gamma, beta, ob, out_f32, rows, D, eps, s, o_ld, o_rpb, o_bs);
+    else if (nch <= 4) launch_ln<4>(ib, x, add, n_add, add_stride, gamma, beta, ob, out_f32, rows, D, eps, s, o_ld, o_rpb, o_bs);
+    else if (nch <= 8) launch_ln<8>(ib, x, add, n_add, add_stride, gamma, beta, ob, out_f32, rows, D, eps, s, o_ld, o_rpb, o_bs);
+    else launch_ln<16>(ib, x, add, n_add, add_stride, gamma, beta, ob, out_f32, rows, D, eps, s, o_ld, o_rpb, o_bs);
     HK_CHECK_LAUNCH("hk_layernorm");
     return HK_OK;
+}
+
+extern "C" int hk_layernorm(const void* x, int32_t in_dtype, const float* add, const float* gamma, const float* beta,
+                            void* out_bf16, float* out_f32, const hk_rows* out_rows, int64_t rows, int32_t D,
+                            float eps, void* stream) {
+    return hk_layernorm_parts(x, in_dtype, add, add ? 1 : 0, 0, gamma, beta, out_bf16, out_f32, out_rows, rows, D, eps, stream);
 }
 
 extern "C" int hk_row_stats(const void* x_bf16, float* stats, int64_t rows, int32_t D, float eps, void* stream) {
@@ -344,6 +419,26 @@ extern "C" int hk_row_stats(const void* x_bf16, float* stats, int64_t rows, int3
     else if (n8 <= 2) hipLaunchKernelGGL((hk_row_stats_kernel<2>), grid, dim3(256), 0, s, xb, stats, rows, D, eps);
     else hipLaunchKernelGGL((hk_row_stats_kernel<4>), grid, dim3(256), 0, s, xb, stats, rows, D, eps);
     HK_CHECK_LAUNCH("hk_row_stats");
+    return HK_OK;
+}
+
+extern "C" int hk_residual_add_parts(void* x_bf16, const float* parts, int32_t n_parts, int64_t part_stride, float* stats,
+                                     int64_t rows, int32_t D, float eps, void* stream) {
+    HK_REQUIRE(x_bf16 && parts, "hk_residual_add_parts: null pointer");
+    HK_REQUIRE(rows > 0 && D > 0 && D % 8 == 0 && D <= 2048 && (rows + 3) / 4 < (1L << 31),
+               "hk_residual_add_parts: bad shape rows=%ld D=%d", (long)rows, D);
+    HK_REQUIRE(n_parts >= 1 && n_parts <= 64 && part_stride % 4 == 0 && (n_parts == 1 || part_stride >= rows * (int64_t)D),
+               "hk_residual_add_parts: bad slices (n_parts=%d, stride=%ld)", n_parts, (long)part_stride);
+    HK_REQUIRE(((uintptr_t)x_bf16 % 16 == 0) && ((uintptr_t)parts % 16 == 0) && ((uintptr_t)stats % 8 == 0),
+               "hk_residual_add_parts: misaligned operands");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    __bf16* xb = reinterpret_cast<__bf16*>(x_bf16);
+    const int n8 = (D + 511) / 512;
+    if (n8 <= 1) hipLaunchKernelGGL((hk_residual_add_parts_kernel<1>), grid, dim3(256), 0, s, xb, parts, n_parts, part_stride, stats, rows, D, eps);
+    else if (n8 <= 2) hipLaunchKernelGGL((hk_residual_add_parts_kernel<2>), grid, dim3(256), 0, s, xb, parts, n_parts, part_stride, stats, rows, D, eps);
+    else hipLaunchKernelGGL((hk_residual_add_parts_kernel<4>), grid, dim3(256), 0, s, xb, parts, n_parts, part_stride, stats, rows, D, eps);
+    HK_CHECK_LAUNCH("hk_residual_add_parts");
     return HK_OK;
 }
 

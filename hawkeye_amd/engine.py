@@ -243,6 +243,49 @@ class HipEncoderEngine:
                            (x, L.HK_DT_F32 if in_f32 else L.HK_DT_BF16, None, gamma.data_ptr(), beta.data_ptr(),
                             ob, of, orow, rows, D, eps), "hk_layernorm", self._tag))
 
+    def _ln_parts(self, plan, parts, n_parts, stride, gamma, beta, ob, of, rows, D, eps, out_rows=None):
+        orow = None
+        if out_rows is not None:
+            r = L.HkRows(*out_rows)
+            plan.keep.append(r)
+            orow = C.byref(r)
+        plan.steps.append((self.lib.hk_layernorm_parts,
+                           (parts, L.HK_DT_F32, parts + 4 * stride, n_parts - 1, stride, gamma.data_ptr(), beta.data_ptr(),
+                            ob, of, orow, rows, D, eps), "hk_layernorm_parts", self._tag))
+
+    @staticmethod
+    def split_k_for(rows: int, N: int, K: int) -> int:
+        """Split-K factor of a dense layer: 1 unless the launch has few output tiles and a long contraction (the
+        Q-Former's 3072 -> 768 layers at small batch: 12 workgroups x 48 K-tiles in a row).  A divisor of K / 64 that
+        brings the launch to about one workgroup per CU, slices of at least 6 K-tiles."""
+        if os.environ.get("HK_SPLIT_K", "1") == "0":
+            return 1
+        tiles = -(-rows // 128) * -(-N // 64)
+        kt = K // 64
+        if tiles > 128 or kt < 24:
+            return 1
+        best = 1
+        for s in range(2, 9):
+            if kt % s == 0 and kt // s >= 6 and tiles * s <= 288:
+                best = s
+        return best
+
+    def split_k_residual(self, M: int, N: int, K: int) -> int:
+        """Split-K factor of a proj / fc2 update of the residual stream on a SMALL call (B = 1 eval calls: fc2 at
+        M = 1568 is 104 workgroups walking 64 K-tiles one after the other, a latency chain).  Only while the slices
+        still fit one workgroup per CU with the deep (4-stage) pipeline and are at least 16 K-tiles long: measured on one
+        box, B = 1: T = 8 5.42 -> 5.07 ms; at T = 12 / 16 (152 / 200 tiles: the slices would need the 2-stage kernel at
+        two workgroups per CU, and the fp32 slices cost more than the shorter chain saves) 5.87 -> 6.01 / 6.05 -> 6.74 ms,
+        so those stay unsplit."""
+        if os.environ.get("HK_SPLIT_K", "1") == "0" or self.residual_dtype != torch.bfloat16 or not self.fold_ln:
+            return 1
+        if -(-M // 256) * -(-N // 256) >= 128:       # the persistent kernel takes it
+            return 1
+        t128 = -(-M // 128) * -(-N // 128)
+        kt = K // 64
+        s = min(int(os.environ.get("HK_SPLIT_K_VIT", "4")), 256 // max(t128, 1), kt // 16)   # the switch: A/B aid
+        return s if s >= 2 else 1
+
     def _build_plan(self, B: int, T: int, Lt: int) -> _Plan:
         cfg, dev, w = self.cfg, self.device, self.w
         plan = _Plan(self.pool)
@@ -266,6 +309,8 @@ class HipEncoderEngine:
             att = plan.buf("att", (M, D), bf16, dev)
             hid = plan.buf("hid", (M, D * cfg.mlp_ratio), bf16, dev)
             kvc = plan.buf("kvc", (M, KVW), bf16, dev)
+            sk2 = self.split_k_residual(M, D, D * cfg.mlp_ratio)
+            parts_x = plan.buf("parts_x", (sk2, M, D), f32, dev) if sk2 > 1 else None
             ids = plan.buf("ids", (B, max(Lt, 1)), torch.int64, dev)
             kbias = plan.buf("kbias", (B, S), f32, dev)
             plan.buf("mask", (B, max(Lt, 1)), torch.int64, dev)
@@ -284,6 +329,12 @@ class HipEncoderEngine:
             fht = plan.buf("fh_t", (B * max(Lt, 1), inter), bf16, dev)   # text-branch temporaries of their own: the branch
             tft = plan.buf("tf_t", (B * max(Lt, 1), d), f32, dev)         # may run beside the query branch (plan.side)
             out = plan.buf("out", (B * nq, cfg.llama_hidden), f32, dev)
+            # split-K partial products of the 3072 -> 768 dense layers at small batch (query / text branch: the
+            # text branch may run beside the query branch, so it has slices of its own)
+            sk_q = self.split_k_for(B * nq, d, inter)
+            sk_t = self.split_k_for(B * Lt, d, inter) if Lt > 0 else 1
+            parts_q = plan.buf("parts_q", (sk_q, B * nq, d), f32, dev) if sk_q > 1 else None
+            parts_t = plan.buf("parts_t", (sk_t, B * Lt, d), f32, dev) if sk_t > 1 else None
 
         P = lambda t: t.data_ptr()  # noqa: E731
         plain = lambda ld: (ld, 0, 0)  # noqa: E731
@@ -302,7 +353,9 @@ class HipEncoderEngine:
             if self.fold_ln:
                 # vit.py:125 norm1 folded into attn.qkv: statistics of the residual stream, then the GEMM on x itself
                 self._tag = "vit.ln_stats"
-                if rpart is not None and i > 0:     # the previous block's fc2 epilogue left the row sums
+                if sk2 > 1 and i > 0:
+                    pass                             # the previous block's split-K tail (hk_residual_add_parts) left (mean, rstd)
+                elif rpart is not None and i > 0:   # the previous block's fc2 epilogue left the row sums
                     plan.steps.append((self.lib.hk_row_stats_finalize, (P(rpart), P(rstat), M, D // 64, cfg.vit_ln_eps),
                                        "hk_row_stats_finalize", self._tag))
                 else:
@@ -339,8 +392,18 @@ class HipEncoderEngine:
             self._tag = "vit.fc2"
             if i == cfg.run_depth - 1:
                 pkw = {}                            # followed by vision_layernorm, which is not folded
-            self._gemm(plan, P(hid), w[o + "fc2.w"], P(x), M, D, D * cfg.mlp_ratio, bias=P(w[o + "fc2.b"]),
-                       residual=P(x), a_rows=plain(D * cfg.mlp_ratio), c_rows=plain(D), r_rows=plain(D), **rkw, **pkw)
+            if sk2 > 1:
+                # small call: K split over workgroups, fp32 slices, then one pass that adds them into the residual
+                # stream and leaves the next block's norm1 statistics (in place of hk_row_stats_finalize)
+                self._gemm(plan, P(hid), w[o + "fc2.w"], P(parts_x), M, D, D * cfg.mlp_ratio, bias=P(w[o + "fc2.b"]),
+                           a_rows=plain(D * cfg.mlp_ratio), c_rows=plain(D), out_f32=True, split_k=sk2, split_stride=M * D)
+                self._tag = "vit.fc2_tail"
+                plan.steps.append((self.lib.hk_residual_add_parts,
+                                   (P(x), P(parts_x), sk2, M * D, P(rstat) if i < cfg.run_depth - 1 else None, M, D,
+                                    cfg.vit_ln_eps), "hk_residual_add_parts", self._tag))
+            else:
+                self._gemm(plan, P(hid), w[o + "fc2.w"], P(x), M, D, D * cfg.mlp_ratio, bias=P(w[o + "fc2.b"]),
+                           residual=P(x), a_rows=plain(D * cfg.mlp_ratio), c_rows=plain(D), r_rows=plain(D), **rkw, **pkw)
         # vision_layernorm (hawkeye_it.py:234) then the K/V projections of every cross layer at once
         self._tag = "vision_layernorm"
         self._ln(plan, P(x), xf32, w["vln.g"], w["vln.b"], P(xn), None, M, D, cfg.vision_ln_eps)
@@ -384,20 +447,34 @@ class HipEncoderEngine:
             # query-branch FFN (Qformer.py:514-517) -> rows [:, :nq] of the next hidden state
             self._gemm(plan, qin_b, w[o + "qi.w"], P(fh), B * nq, inter, d, bias=P(w[o + "qi.b"]),
                        a_rows=qin_rows, c_rows=plain(inter), act=L.HK_ACT_GELU_ERF)
-            self._gemm(plan, P(fh), w[o + "qo.w"], P(tf), B * nq, d, inter, bias=P(w[o + "qo.b"]), residual=qin_f,
-                       a_rows=plain(inter), c_rows=plain(d), r_rows=qin_rows, out_f32=True)
-            self._ln(plan, P(tf), True, w[o + "qo.g"], w[o + "qo.bt"], P(hb), P(hf), B * nq, d, cfg.qf_ln_eps,
-                     out_rows=qrows)
+            if sk_q > 1:
+                self._gemm(plan, P(fh), w[o + "qo.w"], P(parts_q), B * nq, d, inter, bias=P(w[o + "qo.b"]), residual=qin_f,
+                           a_rows=plain(inter), c_rows=plain(d), r_rows=qin_rows, out_f32=True, split_k=sk_q,
+                           split_stride=B * nq * d)
+                self._ln_parts(plan, P(parts_q), sk_q, B * nq * d, w[o + "qo.g"], w[o + "qo.bt"], P(hb), P(hf), B * nq, d,
+                               cfg.qf_ln_eps, out_rows=qrows)
+            else:
+                self._gemm(plan, P(fh), w[o + "qo.w"], P(tf), B * nq, d, inter, bias=P(w[o + "qo.b"]), residual=qin_f,
+                           a_rows=plain(inter), c_rows=plain(d), r_rows=qin_rows, out_f32=True)
+                self._ln(plan, P(tf), True, w[o + "qo.g"], w[o + "qo.bt"], P(hb), P(hf), B * nq, d, cfg.qf_ln_eps,
+                         out_rows=qrows)
             # text-branch FFN (Qformer.py:509-512); its last-layer result is never read (hawkeye_it.py:269)
             if Lt > 0 and not last:
                 toff = nq * d
                 start = len(plan.steps)
                 self._gemm(plan, P(ab) + toff * eb, w[o + "ti.w"], P(fht), B * Lt, inter, d, bias=P(w[o + "ti.b"]),
                            a_rows=trows, c_rows=plain(inter), act=L.HK_ACT_GELU_ERF)
-                self._gemm(plan, P(fht), w[o + "to.w"], P(tft), B * Lt, d, inter, bias=P(w[o + "to.b"]),
-                           residual=P(af) + toff * 4, a_rows=plain(inter), c_rows=plain(d), r_rows=trows, out_f32=True)
-                self._ln(plan, P(tft), True, w[o + "to.g"], w[o + "to.bt"], P(hb) + toff * eb, P(hf) + toff * 4,
-                         B * Lt, d, cfg.qf_ln_eps, out_rows=trows)
+                if sk_t > 1:
+                    self._gemm(plan, P(fht), w[o + "to.w"], P(parts_t), B * Lt, d, inter, bias=P(w[o + "to.b"]),
+                               residual=P(af) + toff * 4, a_rows=plain(inter), c_rows=plain(d), r_rows=trows, out_f32=True,
+                               split_k=sk_t, split_stride=B * Lt * d)
+                    self._ln_parts(plan, P(parts_t), sk_t, B * Lt * d, w[o + "to.g"], w[o + "to.bt"], P(hb) + toff * eb,
+                                   P(hf) + toff * 4, B * Lt, d, cfg.qf_ln_eps, out_rows=trows)
+                else:
+                    self._gemm(plan, P(fht), w[o + "to.w"], P(tft), B * Lt, d, inter, bias=P(w[o + "to.b"]),
+                               residual=P(af) + toff * 4, a_rows=plain(inter), c_rows=plain(d), r_rows=trows, out_f32=True)
+                    self._ln(plan, P(tft), True, w[o + "to.g"], w[o + "to.bt"], P(hb) + toff * eb, P(hf) + toff * 4,
+                             B * Lt, d, cfg.qf_ln_eps, out_rows=trows)
                 # reads rows [nq:] of ab / af (complete at `fork`), writes rows [nq:] of hb / hf (read by the next
                 # layer's qkv GEMM, the step after `end`); the query branch touches rows [:nq] only
                 plan.side.append((fork, start, len(plan.steps)))

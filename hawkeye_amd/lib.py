@@ -32,6 +32,7 @@ class HkGemmDesc(C.Structure):
         ("act", C.c_int32), ("out_dtype", C.c_int32), ("res_dtype", C.c_int32), ("scale_cols", C.c_int32),
         ("scale", C.c_float),
         ("row_stats", C.c_void_p), ("col_c", C.c_void_p), ("row_part", C.c_void_p),
+        ("split_k", C.c_int32), ("split_stride", C.c_int64),
     ]
 
 
@@ -75,7 +76,11 @@ SYMBOLS = {
     "hk_flash_attn_bf16": (C.c_int, [C.POINTER(HkAttnDesc), C.c_void_p]),
     "hk_layernorm": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.POINTER(HkRows), C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
+    "hk_layernorm_parts": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.POINTER(HkRows), C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
     "hk_row_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
+    "hk_residual_add_parts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_int32,
+                                        C.c_float, C.c_void_p]),
     "hk_row_stats_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
     "hk_patchify_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_void_p]),

@@ -31,7 +31,8 @@ def _need(t: torch.Tensor, dtype, name: str):
 
 def gemm_desc(A, W, C_out, M, N, K, *, bias=None, residual=None, a_rows: Rows, c_rows: Rows,
               r_rows: Rows = (0, 0, 0), ldw=None, act=L.HK_ACT_NONE, out_f32=False, res_bf16=False,
-              scale_cols=0, scale=1.0, row_stats=None, col_c=None, row_part=None) -> L.HkGemmDesc:
+              scale_cols=0, scale=1.0, row_stats=None, col_c=None, row_part=None, split_k=0,
+              split_stride=0) -> L.HkGemmDesc:
     """Raw-pointer descriptor; A/W/C_out/bias/residual (and row_stats/col_c: LayerNorm of A folded into the GEMM,
     see include/hawkeye_hip.h) are integer device addresses."""
     d = L.HkGemmDesc()
@@ -47,6 +48,7 @@ def gemm_desc(A, W, C_out, M, N, K, *, bias=None, residual=None, a_rows: Rows, c
     d.scale_cols = scale_cols
     d.scale = scale
     d.row_stats, d.col_c, d.row_part = row_stats, col_c, row_part
+    d.split_k, d.split_stride = split_k, split_stride
     return d
 
 
@@ -186,6 +188,44 @@ def layernorm_raw(x_ptr, in_f32: bool, add_ptr, gamma_ptr, beta_ptr, out_b_ptr, 
     orow = C.byref(L.HkRows(*out_rows)) if out_rows is not None else None
     L.check(L.load().hk_layernorm(x_ptr, L.HK_DT_F32 if in_f32 else L.HK_DT_BF16, add_ptr, gamma_ptr, beta_ptr,
                                   out_b_ptr, out_f_ptr, orow, rows, D, eps, _stream()), "hk_layernorm")
+
+
+def linear_split_k(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], residual: Optional[torch.Tensor],
+                   split_k: int) -> torch.Tensor:
+    """Split-K partial products [split_k, M, N] fp32 of x @ w.T; slice 0 carries bias and residual (fp32 [M, N])."""
+    _need(x, torch.bfloat16, "x")
+    _need(w, torch.bfloat16, "w")
+    M, K = x.shape
+    N = w.shape[0]
+    parts = torch.empty((split_k, M, N), dtype=torch.float32, device=x.device)
+    d = gemm_desc(x.data_ptr(), w.data_ptr(), parts.data_ptr(), M, N, K, bias=_ptr(bias), residual=_ptr(residual),
+                  a_rows=(x.stride(0), 0, 0), c_rows=(N, 0, 0), r_rows=(N, 0, 0), ldw=w.stride(0), out_f32=True,
+                  split_k=split_k, split_stride=M * N)
+    run_gemm(d)
+    return parts
+
+
+def residual_add_parts(x: torch.Tensor, parts: torch.Tensor, eps: float, want_stats: bool = True):
+    """x (bf16 [rows, D], in place) += parts.sum(0) (fp32 [P, rows, D]); returns (mean, rstd) [rows, 2] of the stored rows."""
+    _need(x, torch.bfloat16, "x")
+    _need(parts, torch.float32, "parts")
+    P, rows, D = parts.shape
+    st = torch.empty((rows, 2), dtype=torch.float32, device=x.device) if want_stats else None
+    L.check(L.load().hk_residual_add_parts(x.data_ptr(), parts.data_ptr(), P, rows * D, _ptr(st), rows, D, eps, _stream()),
+            "hk_residual_add_parts")
+    return st
+
+
+def layernorm_parts(parts: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float):
+    """LayerNorm of sum(parts, 0); parts fp32 [P, rows, D] (split-K slices).  Returns (bf16, fp32)."""
+    _need(parts, torch.float32, "parts")
+    P, rows, D = parts.shape
+    ob = torch.empty((rows, D), dtype=torch.bfloat16, device=parts.device)
+    of = torch.empty((rows, D), dtype=torch.float32, device=parts.device)
+    L.check(L.load().hk_layernorm_parts(parts.data_ptr(), L.HK_DT_F32, parts.data_ptr() + 4 * rows * D, P - 1, rows * D,
+                                        gamma.data_ptr(), beta.data_ptr(), ob.data_ptr(), of.data_ptr(), None, rows, D,
+                                        eps, _stream()), "hk_layernorm_parts")
+    return ob, of
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, *,

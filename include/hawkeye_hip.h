@@ -82,6 +82,13 @@ typedef struct hk_gemm_desc {
      * taken on the bf16 values as stored (the matrix the consumer reads); hk_row_stats_finalize turns them into (mean, rstd).
      * Needs N % 128 == 0 and the bf16 in-place residual epilogue; NULL when unused. */
     float* row_part;        /* [M][N / 64][2] fp32 */
+    /* Split-K for problems with few output tiles and a long contraction (the Q-Former's 3072 -> 768 dense layers on a
+     * few hundred rows: 12 workgroups walking 48 K-tiles one after the other).  split_k > 1: slice z < split_k
+     * multiplies K-tiles [z * ceil(KT / split_k), ...) and writes its fp32 partial product to C + z * split_stride
+     * (elements); slice 0 carries bias and residual.  The consumer sums the slices (hk_layernorm_parts).  Needs fp32
+     * output, no activation, no folded LayerNorm, no row_part.  0 or 1 = off. */
+    int32_t split_k;
+    int64_t split_stride;
 } hk_gemm_desc;
 
 int hk_gemm_bf16(const hk_gemm_desc* d, void* stream);
@@ -119,11 +126,25 @@ int hk_layernorm(const void* x, int32_t in_dtype, const float* add, const float*
                  void* out_bf16, float* out_f32, const hk_rows* out_rows, int64_t rows, int32_t D, float eps,
                  void* stream);
 
+/* hk_layernorm with n_add fp32 addends add[a * add_stride + row * D + col], a < n_add, summed in index order before the
+ * norm: the partial products of a split-K GEMM (hk_gemm_desc.split_k) are reduced here instead of in a pass of their
+ * own, so dense -> (+ residual) -> LayerNorm (Qformer.py:314-317, 402-405) stays two launches however K is split. */
+int hk_layernorm_parts(const void* x, int32_t in_dtype, const float* add, int32_t n_add, int64_t add_stride,
+                       const float* gamma, const float* beta, void* out_bf16, float* out_f32, const hk_rows* out_rows,
+                       int64_t rows, int32_t D, float eps, void* stream);
+
 /* Row statistics of a bf16 matrix: stats[m] = (mean_m, 1 / sqrt(var_m + eps)), two-pass fp32 over the row held in
  * registers (the same arithmetic as hk_layernorm's).  Feeds hk_gemm_desc.row_stats: the statistics half of
  * nn.LayerNorm vit.py:108,114 when the normalisation itself is folded into the consuming GEMM.
  * x [rows, D] plain, D % 8 == 0, D <= 2048; stats [rows][2] fp32. */
 int hk_row_stats(const void* x_bf16, float* stats, int64_t rows, int32_t D, float eps, void* stream);
+
+/* Tail of a split-K proj / fc2 (vit.py:126-127) on a small call: x (bf16 [rows, D], in place) += sum over a < n_parts of
+ * parts[a * part_stride + row * D + col] (fp32 slices of hk_gemm_desc.split_k; slice 0 carries the bias), rounded once;
+ * stats[row] = (mean, rstd) of the row as stored (NULL: not wanted) -- what hk_row_stats would return for it -- for the
+ * GEMM that consumes x with its LayerNorm folded in.  D % 8 == 0, D <= 2048. */
+int hk_residual_add_parts(void* x_bf16, const float* parts, int32_t n_parts, int64_t part_stride, float* stats, int64_t rows,
+                          int32_t D, float eps, void* stream);
 
 /* stats[m] = (mean, rstd) from the per-group sums a GEMM left in hk_gemm_desc.row_part: part [rows][groups][2],
  * D = 64 * groups columns per row; sums combined in float64, var = E[x^2] - mean^2 clamped at 0. */

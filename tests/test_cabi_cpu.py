@@ -33,9 +33,10 @@ def test_version_and_arch():
 
 def test_struct_layout_matches_header():
     # hk_rows: 3 x int64; hk_gemm_desc: 5 ptr, 3 int32 (+pad), rows, int64, rows, rows, 4 int32 + float (+pad),
-    # then row_stats, col_c, row_part
+    # then row_stats, col_c, row_part, split_k (+pad), split_stride
     assert C.sizeof(L.HkRows) == 24
-    assert C.sizeof(L.HkGemmDesc) == 5 * 8 + 16 + 24 + 8 + 24 + 24 + 24 + 3 * 8   # 4 int32 + float, padded to 8
+    assert C.sizeof(L.HkGemmDesc) == 5 * 8 + 16 + 24 + 8 + 24 + 24 + 24 + 3 * 8 + 8 + 8   # 4 int32 + float, padded to 8
+    assert L.HkGemmDesc.split_k.offset == 5 * 8 + 16 + 24 + 8 + 24 + 24 + 24 + 3 * 8 and L.HkGemmDesc.split_stride.offset % 8 == 0
     assert C.sizeof(L.HkAttnDesc) == 5 * 8 + 16 + 8 * 8 + 8   # + head_dim, causal
 
 
@@ -48,6 +49,10 @@ def test_bad_descriptors_are_rejected_with_text():
     d.M, d.N, d.K = 16, 16, 48
     assert lib.hk_gemm_bf16(C.byref(d), None) == 1
     assert "multiple of 64" in L.last_error()
+    d.K, d.N, d.split_k = 128, 64, 2          # split-K needs fp32 output
+    d.a_rows.ld = d.ldw = 128
+    d.c_rows.ld = 64
+    assert lib.hk_gemm_bf16(C.byref(d), None) == 1 and "split_k" in L.last_error()
     a = L.HkAttnDesc()
     assert lib.hk_flash_attn_bf16(C.byref(a), None) == 1
     assert lib.hk_layernorm(None, 0, None, None, None, None, None, None, 4, 64, 1e-6, None) == 1

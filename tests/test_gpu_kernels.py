@@ -188,6 +188,52 @@ def test_gemm_row_part_feeds_the_next_layernorm(M, N, K):
     assert torch.allclose(st[:, 1], st_ref[:, 1], rtol=2e-5)
 
 
+@pytest.mark.parametrize("M,N,K,S", [(96, 768, 3072, 6), (32, 768, 3072, 8), (200, 768, 3072, 4), (96, 768, 768, 3),
+                                     (2352, 1024, 4096, 2), (130, 144, 320, 5)])
+def test_gemm_split_k_partials_and_layernorm_of_their_sum(M, N, K, S):
+    """hk_gemm_desc.split_k: slice z multiplies its own K range; slice 0 carries bias + residual; the slices sum to the
+    unsplit GEMM (fp32 reassociation only), and hk_layernorm_parts normalises the sum without a reduction pass."""
+    x = _rand((M, K), 41, dtype=torch.bfloat16)
+    w = _rand((N, K), 42, 0.05, dtype=torch.bfloat16)
+    b = _rand((N,), 43)
+    res = _rand((M, N), 44)
+    parts = ops.linear_split_k(x, w, b, res, S)
+    assert parts.shape == (S, M, N)
+    ref = x.float() @ w.float().t() + b + res
+    kper = -(-(K // 64) // S) * 64
+    for z in range(S):                       # every slice is exactly its K range
+        pz = x[:, z * kper:(z + 1) * kper].float() @ w[:, z * kper:(z + 1) * kper].float().t()
+        if z == 0:
+            pz = pz + b + res
+        assert _rel(parts[z], pz) < 2e-5, z
+    whole = ops.linear(x, w, b, residual=res, out_dtype=torch.float32)
+    assert _rel(parts.sum(0), whole) < 1e-5 and _rel(whole, ref) < 1e-4
+    if N % 4 == 0 and N <= 4096:
+        g, bt = _rand((N,), 45, 0.3) + 1.0, _rand((N,), 46, 0.3)
+        ob, of = ops.layernorm_parts(parts, g, bt, 1e-12)
+        want = torch.nn.functional.layer_norm(parts.sum(0), (N,), g, bt, 1e-12)
+        assert _rel(of, want) < 1e-5 and _rel(ob.float(), want) < 1e-2
+        ob2, of2 = ops.layernorm_parts(parts, g, bt, 1e-12)
+        assert torch.equal(of, of2)              # fixed summation order: bit-reproducible
+
+
+@pytest.mark.parametrize("rows,D,S", [(2352, 1024, 3), (197, 1024, 2), (64, 256, 4), (5, 1536, 1)])
+def test_residual_add_parts_updates_the_stream_and_leaves_row_statistics(rows, D, S):
+    """Tail of a split-K fc2 on a small call: x += sum of the slices, rounded once; (mean, rstd) of the rows as stored."""
+    x = (_rand((rows, D), 51) * 2 + _rand((rows, 1), 52, 1.5)).to(torch.bfloat16)
+    parts = _rand((S, rows, D), 53)
+    want = (x.float() + parts.sum(0)).to(torch.bfloat16)
+    got = x.clone()
+    st = ops.residual_add_parts(got, parts, 1e-6)
+    # one rounding of the fp32 sum; the slice order is fixed, torch's sum may associate differently: allow 1 bf16 ulp
+    assert (got.float() - want.float()).abs().max() <= 2 ** -7 * want.float().abs().max()
+    assert (got != want).float().mean() < 1e-3
+    ref = ops.row_stats(got, 1e-6)
+    assert torch.equal(st, ref)
+    again = x.clone()
+    assert ops.residual_add_parts(again, parts, 1e-6, want_stats=False) is None and torch.equal(again, got)
+
+
 def test_gemm_rejects_bad_shapes():
     x = _rand((8, 48), 1, dtype=torch.bfloat16)
     w = _rand((16, 48), 2, dtype=torch.bfloat16)

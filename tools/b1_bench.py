@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""B=1 call latency (the recursive-grounding shape) with and without hipGraph replay (HK_GRAPH=0/1)."""
+"""B=1 call latency (the recursive-grounding shape); the HK_* switches in the environment are printed with each line
+(run it twice in one gpurun call for a same-box A/B, e.g. HK_SPLIT_K=0 / 1, HK_GRAPH=0 / 1)."""
 import os, sys, time
 import torch
 
@@ -27,4 +28,5 @@ for B, T in ((1, 1), (1, 8), (1, 12), (1, 16), (4, 12), (4, 16)):
         model.encode_img(image, (ids, mask))
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 1e3 / n
-    print(f"HK_GRAPH={os.environ.get('HK_GRAPH','1')} B={B} T={T}: {ms:.3f} ms/call  {B/ms*1e3:.1f} clips/s", flush=True)
+    tag = " ".join(f"{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith("HK_"))
+    print(f"[{tag}] B={B} T={T}: {ms:.3f} ms/call  {B/ms*1e3:.1f} clips/s", flush=True)
