@@ -89,10 +89,16 @@ MAX_PLANS = 64      # host-side descriptor sets kept per engine (LRU); device me
 
 
 class HipEncoderEngine:
-    def __init__(self, cfg: EncoderConfig, device="cuda", residual_dtype=torch.bfloat16):
+    def __init__(self, cfg: EncoderConfig, device="cuda", residual_dtype=torch.bfloat16, halves=("vit", "qformer")):
         """residual_dtype: storage type of the ViT residual stream `x` (bf16 halves the proj / fc2
         epilogue and LayerNorm traffic; the reference's CUDA autocast path keeps it in fp16).
-        Arithmetic is fp32 either way: each update is acc + bias + float(x), rounded once."""
+        Arithmetic is fp32 either way: each update is acc + bias + float(x), rounded once.
+        halves: which part of the path this engine runs -- both (default), or one of them when the model is placed on
+        two devices (set_device_ids, hawkeye_it.py:197-211): the "vit" engine ends with image_embeds (plan.ws["xn"]),
+        the "qformer" engine starts from them."""
+        self.halves = tuple(halves)
+        if not self.halves or any(h not in ("vit", "qformer") for h in self.halves):
+            raise RuntimeError(f"halves must be a non-empty subset of ('vit', 'qformer'), got {halves!r}")
         if residual_dtype not in (torch.bfloat16, torch.float32):
             raise RuntimeError("residual_dtype must be torch.bfloat16 or torch.float32")
         self.residual_dtype = residual_dtype
@@ -136,6 +142,7 @@ class HipEncoderEngine:
         Operands that already exist with the same shape are overwritten in place: cached plans hold their
         addresses."""
         cfg, dev = self.cfg, self.device
+        parts = tuple(h for h in parts if h in self.halves)     # an engine packs only the half it runs
         w: Dict[str, torch.Tensor] = {}
 
         def f32(key):
@@ -300,188 +307,194 @@ class HipEncoderEngine:
         KVW = 2 * d * self.n_cross
         bf16, f32 = torch.bfloat16, torch.float32
         with torch.cuda.device(dev):
-            pa = plan.buf("patches", (M, Kp), bf16, dev)
-            x = plan.buf("x", (M, D), self.residual_dtype, dev)
-            xn = plan.buf("xn", (M, D), bf16, dev)
-            rstat = plan.buf("rstat", ((M + 255) // 256 * 256, 2), f32, dev) if self.fold_ln else None   # whole 256-row tiles are read
-            rpart = plan.buf("rpart", (M, D // 64, 2), f32, dev) if self.fold_ln and self.epi_stats else None
-            qkv = plan.buf("qkv", (M, 3 * D), bf16, dev)
-            att = plan.buf("att", (M, D), bf16, dev)
-            hid = plan.buf("hid", (M, D * cfg.mlp_ratio), bf16, dev)
-            kvc = plan.buf("kvc", (M, KVW), bf16, dev)
-            sk2 = self.split_k_residual(M, D, D * cfg.mlp_ratio)
-            parts_x = plan.buf("parts_x", (sk2, M, D), f32, dev) if sk2 > 1 else None
+            run_vit, run_qf = "vit" in self.halves, "qformer" in self.halves
+            xn = plan.buf("xn", (M, D), bf16, dev)          # image_embeds: the hand-over point between the two halves
             ids = plan.buf("ids", (B, max(Lt, 1)), torch.int64, dev)
             kbias = plan.buf("kbias", (B, S), f32, dev)
             plan.buf("mask", (B, max(Lt, 1)), torch.int64, dev)
-            hf = plan.buf("hf", (B * S, d), f32, dev)
-            hb = plan.buf("hb", (B * S, d), bf16, dev)
-            qqkv = plan.buf("qqkv", (B * S, 3 * d), bf16, dev)
-            ctx = plan.buf("ctx", (B * S, d), bf16, dev)
-            tf = plan.buf("tf", (B * S, d), f32, dev)
-            af = plan.buf("af", (B * S, d), f32, dev)
-            ab = plan.buf("ab", (B * S, d), bf16, dev)
-            cq = plan.buf("cq", (B * nq, d), bf16, dev)
-            cctx = plan.buf("cctx", (B * nq, d), bf16, dev)
-            cf = plan.buf("cf", (B * nq, d), f32, dev)
-            cb = plan.buf("cb", (B * nq, d), bf16, dev)
-            fh = plan.buf("fh", (B * nq, inter), bf16, dev)
-            fht = plan.buf("fh_t", (B * max(Lt, 1), inter), bf16, dev)   # text-branch temporaries of their own: the branch
-            tft = plan.buf("tf_t", (B * max(Lt, 1), d), f32, dev)         # may run beside the query branch (plan.side)
-            out = plan.buf("out", (B * nq, cfg.llama_hidden), f32, dev)
-            # split-K partial products of the 3072 -> 768 dense layers at small batch (query / text branch: the
-            # text branch may run beside the query branch, so it has slices of its own)
-            sk_q = self.split_k_for(B * nq, d, inter)
-            sk_t = self.split_k_for(B * Lt, d, inter) if Lt > 0 else 1
-            parts_q = plan.buf("parts_q", (sk_q, B * nq, d), f32, dev) if sk_q > 1 else None
-            parts_t = plan.buf("parts_t", (sk_t, B * Lt, d), f32, dev) if sk_t > 1 else None
+            sk2 = sk_q = sk_t = 1
+            if run_vit:
+                pa = plan.buf("patches", (M, Kp), bf16, dev)
+                x = plan.buf("x", (M, D), self.residual_dtype, dev)
+                rstat = plan.buf("rstat", ((M + 255) // 256 * 256, 2), f32, dev) if self.fold_ln else None   # whole 256-row tiles are read
+                rpart = plan.buf("rpart", (M, D // 64, 2), f32, dev) if self.fold_ln and self.epi_stats else None
+                qkv = plan.buf("qkv", (M, 3 * D), bf16, dev)
+                att = plan.buf("att", (M, D), bf16, dev)
+                hid = plan.buf("hid", (M, D * cfg.mlp_ratio), bf16, dev)
+                sk2 = self.split_k_residual(M, D, D * cfg.mlp_ratio)
+                parts_x = plan.buf("parts_x", (sk2, M, D), f32, dev) if sk2 > 1 else None
+            if run_qf:
+                kvc = plan.buf("kvc", (M, KVW), bf16, dev)
+                hf = plan.buf("hf", (B * S, d), f32, dev)
+                hb = plan.buf("hb", (B * S, d), bf16, dev)
+                qqkv = plan.buf("qqkv", (B * S, 3 * d), bf16, dev)
+                ctx = plan.buf("ctx", (B * S, d), bf16, dev)
+                tf = plan.buf("tf", (B * S, d), f32, dev)
+                af = plan.buf("af", (B * S, d), f32, dev)
+                ab = plan.buf("ab", (B * S, d), bf16, dev)
+                cq = plan.buf("cq", (B * nq, d), bf16, dev)
+                cctx = plan.buf("cctx", (B * nq, d), bf16, dev)
+                cf = plan.buf("cf", (B * nq, d), f32, dev)
+                cb = plan.buf("cb", (B * nq, d), bf16, dev)
+                fh = plan.buf("fh", (B * nq, inter), bf16, dev)
+                fht = plan.buf("fh_t", (B * max(Lt, 1), inter), bf16, dev)   # text-branch temporaries of their own: the branch
+                tft = plan.buf("tf_t", (B * max(Lt, 1), d), f32, dev)         # may run beside the query branch (plan.side)
+                out = plan.buf("out", (B * nq, cfg.llama_hidden), f32, dev)
+                # split-K partial products of the 3072 -> 768 dense layers at small batch (query / text branch: the
+                # text branch may run beside the query branch, so it has slices of its own)
+                sk_q = self.split_k_for(B * nq, d, inter)
+                sk_t = self.split_k_for(B * Lt, d, inter) if Lt > 0 else 1
+                parts_q = plan.buf("parts_q", (sk_q, B * nq, d), f32, dev) if sk_q > 1 else None
+                parts_t = plan.buf("parts_t", (sk_t, B * Lt, d), f32, dev) if sk_t > 1 else None
 
         P = lambda t: t.data_ptr()  # noqa: E731
         plain = lambda ld: (ld, 0, 0)  # noqa: E731
-
-        # ---- ViT: patch-embed GEMM (+bias, + position table broadcast over the batch) ----
-        # step 0 (patchify) and the table pointer are bound at run time
-        xf32 = self.residual_dtype == torch.float32
-        rkw = dict(out_f32=xf32, res_bf16=not xf32)   # in-place residual-stream update
-        self._tag = "vit.patch_embed"
-        plan.patch_desc = self._gemm(plan, P(pa), w["patch.w"], P(x), M, D, Kp, bias=P(w["patch.b"]), residual=0,
-                                     a_rows=plain(Kp), c_rows=plain(D), r_rows=(D, N, 0), out_f32=xf32)
         qscale = (64 ** -0.5) * LOG2E
-        for i in range(cfg.run_depth):
-            o = f"vit.{i}."
-            fold = {}
-            if self.fold_ln:
-                # vit.py:125 norm1 folded into attn.qkv: statistics of the residual stream, then the GEMM on x itself
-                self._tag = "vit.ln_stats"
-                if sk2 > 1 and i > 0:
-                    pass                             # the previous block's split-K tail (hk_residual_add_parts) left (mean, rstd)
-                elif rpart is not None and i > 0:   # the previous block's fc2 epilogue left the row sums
-                    plan.steps.append((self.lib.hk_row_stats_finalize, (P(rpart), P(rstat), M, D // 64, cfg.vit_ln_eps),
-                                       "hk_row_stats_finalize", self._tag))
-                else:
-                    plan.steps.append((self.lib.hk_row_stats, (P(x), P(rstat), M, D, cfg.vit_ln_eps), "hk_row_stats", self._tag))
-                fold = dict(row_stats=P(rstat), col_c=P(w[o + "qkv.c"]))
-            else:
-                self._tag = "vit.ln"
-                self._ln(plan, P(x), xf32, w[o + "ln1.g"], w[o + "ln1.b"], P(xn), None, M, D, cfg.vit_ln_eps)
-            self._tag = "vit.qkv"
-            self._gemm(plan, P(x) if self.fold_ln else P(xn), w[o + "qkv.w"], P(qkv), M, 3 * D, D, bias=P(w[o + "qkv.b"]),
-                       a_rows=plain(D), c_rows=plain(3 * D), scale_cols=D, scale=qscale, **fold)
-            self._tag = "vit.attn"
-            self._attn(plan, P(qkv), P(qkv) + 2 * D, P(qkv) + 4 * D, P(att), B, Hv, N, N,
-                       3 * D, 3 * D, 3 * D, D, N * 3 * D, N * 3 * D, N * 3 * D, N * D)
-            self._tag = "vit.proj"
-            pkw = dict(row_part=P(rpart)) if rpart is not None else {}
-            self._gemm(plan, P(att), w[o + "proj.w"], P(x), M, D, D, bias=P(w[o + "proj.b"]), residual=P(x),
-                       a_rows=plain(D), c_rows=plain(D), r_rows=plain(D), **rkw, **pkw)
-            if self.fold_ln:
-                self._tag = "vit.ln_stats"
-                if rpart is not None:
-                    plan.steps.append((self.lib.hk_row_stats_finalize, (P(rpart), P(rstat), M, D // 64, cfg.vit_ln_eps),
-                                       "hk_row_stats_finalize", self._tag))
-                else:
-                    plan.steps.append((self.lib.hk_row_stats, (P(x), P(rstat), M, D, cfg.vit_ln_eps), "hk_row_stats", self._tag))
-                fold = dict(row_stats=P(rstat), col_c=P(w[o + "fc1.c"]))
-            else:
-                self._tag = "vit.ln"
-                self._ln(plan, P(x), xf32, w[o + "ln2.g"], w[o + "ln2.b"], P(xn), None, M, D, cfg.vit_ln_eps)
-            self._tag = "vit.fc1_gelu"
-            self._gemm(plan, P(x) if self.fold_ln else P(xn), w[o + "fc1.w"], P(hid), M, D * cfg.mlp_ratio, D,
-                       bias=P(w[o + "fc1.b"]), a_rows=plain(D), c_rows=plain(D * cfg.mlp_ratio),
-                       act=L.HK_ACT_GELU_ERF, **fold)
-            self._tag = "vit.fc2"
-            if i == cfg.run_depth - 1:
-                pkw = {}                            # followed by vision_layernorm, which is not folded
-            if sk2 > 1:
-                # small call: K split over workgroups, fp32 slices, then one pass that adds them into the residual
-                # stream and leaves the next block's norm1 statistics (in place of hk_row_stats_finalize)
-                self._gemm(plan, P(hid), w[o + "fc2.w"], P(parts_x), M, D, D * cfg.mlp_ratio, bias=P(w[o + "fc2.b"]),
-                           a_rows=plain(D * cfg.mlp_ratio), c_rows=plain(D), out_f32=True, split_k=sk2, split_stride=M * D)
-                self._tag = "vit.fc2_tail"
-                plan.steps.append((self.lib.hk_residual_add_parts,
-                                   (P(x), P(parts_x), sk2, M * D, P(rstat) if i < cfg.run_depth - 1 else None, M, D,
-                                    cfg.vit_ln_eps), "hk_residual_add_parts", self._tag))
-            else:
-                self._gemm(plan, P(hid), w[o + "fc2.w"], P(x), M, D, D * cfg.mlp_ratio, bias=P(w[o + "fc2.b"]),
-                           residual=P(x), a_rows=plain(D * cfg.mlp_ratio), c_rows=plain(D), r_rows=plain(D), **rkw, **pkw)
-        # vision_layernorm (hawkeye_it.py:234) then the K/V projections of every cross layer at once
-        self._tag = "vision_layernorm"
-        self._ln(plan, P(x), xf32, w["vln.g"], w["vln.b"], P(xn), None, M, D, cfg.vision_ln_eps)
-        plan.vit_end = len(plan.steps)
-        self._tag = "qformer.cross_kv"
-        self._gemm(plan, P(xn), w["ckv.w"], P(kvc), M, KVW, D, bias=P(w["ckv.b"]), a_rows=plain(D), c_rows=plain(KVW))
 
-        # ---- Q-Former ----
-        self._tag = "qformer"
-        plan.steps.append((self.lib.hk_qformer_embed_ln,
-                           (P(w["query"]), P(w["emb.word"]), P(w["emb.pos"]), P(ids) if Lt > 0 else None,
-                            P(w["emb.ln.g"]), P(w["emb.ln.b"]), P(hf), P(hb), B, nq, Lt, d, w["emb.word"].shape[0],
-                            cfg.qf_ln_eps), "hk_qformer_embed_ln", "qformer"))
-        qrows = (d, nq, S * d)
-        trows = (d, Lt, S * d)
-        eb = 2  # bytes per bf16
-        ci = 0
-        for i in range(cfg.qf_layers):
-            o = f"qf.{i}."
-            last = i == cfg.qf_layers - 1
-            self._gemm(plan, P(hb), w[o + "qkv.w"], P(qqkv), B * S, 3 * d, d, bias=P(w[o + "qkv.b"]),
-                       a_rows=plain(d), c_rows=plain(3 * d), scale_cols=d, scale=qscale)
-            self._attn(plan, P(qqkv), P(qqkv) + d * eb, P(qqkv) + 2 * d * eb, P(ctx), B, Hq, S, S,
-                       3 * d, 3 * d, 3 * d, d, S * 3 * d, S * 3 * d, S * 3 * d, S * d, key_bias=P(kbias))
-            self._gemm(plan, P(ctx), w[o + "ao.w"], P(tf), B * S, d, d, bias=P(w[o + "ao.b"]), residual=P(hf),
-                       a_rows=plain(d), c_rows=plain(d), r_rows=plain(d), out_f32=True)
-            self._ln(plan, P(tf), True, w[o + "ao.g"], w[o + "ao.bt"], P(ab), P(af), B * S, d, cfg.qf_ln_eps)
-            fork = len(plan.steps)
-            if i % cfg.cross_attention_freq == 0:
-                self._gemm(plan, P(ab), w[o + "cq.w"], P(cq), B * nq, d, d, bias=P(w[o + "cq.b"]),
-                           a_rows=qrows, c_rows=plain(d), scale_cols=d, scale=qscale)
-                self._attn(plan, P(cq), P(kvc) + ci * 2 * d * eb, P(kvc) + (ci * 2 + 1) * d * eb, P(cctx), B, Hq, nq, N,
-                           d, KVW, KVW, d, nq * d, N * KVW, N * KVW, nq * d)
-                self._gemm(plan, P(cctx), w[o + "co.w"], P(tf), B * nq, d, d, bias=P(w[o + "co.b"]), residual=P(af),
-                           a_rows=plain(d), c_rows=plain(d), r_rows=qrows, out_f32=True)
-                self._ln(plan, P(tf), True, w[o + "co.g"], w[o + "co.bt"], P(cb), P(cf), B * nq, d, cfg.qf_ln_eps)
-                qin_b, qin_f, qin_rows = P(cb), P(cf), plain(d)
-                ci += 1
-            else:
-                qin_b, qin_f, qin_rows = P(ab), P(af), qrows
-            # query-branch FFN (Qformer.py:514-517) -> rows [:, :nq] of the next hidden state
-            self._gemm(plan, qin_b, w[o + "qi.w"], P(fh), B * nq, inter, d, bias=P(w[o + "qi.b"]),
-                       a_rows=qin_rows, c_rows=plain(inter), act=L.HK_ACT_GELU_ERF)
-            if sk_q > 1:
-                self._gemm(plan, P(fh), w[o + "qo.w"], P(parts_q), B * nq, d, inter, bias=P(w[o + "qo.b"]), residual=qin_f,
-                           a_rows=plain(inter), c_rows=plain(d), r_rows=qin_rows, out_f32=True, split_k=sk_q,
-                           split_stride=B * nq * d)
-                self._ln_parts(plan, P(parts_q), sk_q, B * nq * d, w[o + "qo.g"], w[o + "qo.bt"], P(hb), P(hf), B * nq, d,
-                               cfg.qf_ln_eps, out_rows=qrows)
-            else:
-                self._gemm(plan, P(fh), w[o + "qo.w"], P(tf), B * nq, d, inter, bias=P(w[o + "qo.b"]), residual=qin_f,
-                           a_rows=plain(inter), c_rows=plain(d), r_rows=qin_rows, out_f32=True)
-                self._ln(plan, P(tf), True, w[o + "qo.g"], w[o + "qo.bt"], P(hb), P(hf), B * nq, d, cfg.qf_ln_eps,
-                         out_rows=qrows)
-            # text-branch FFN (Qformer.py:509-512); its last-layer result is never read (hawkeye_it.py:269)
-            if Lt > 0 and not last:
-                toff = nq * d
-                start = len(plan.steps)
-                self._gemm(plan, P(ab) + toff * eb, w[o + "ti.w"], P(fht), B * Lt, inter, d, bias=P(w[o + "ti.b"]),
-                           a_rows=trows, c_rows=plain(inter), act=L.HK_ACT_GELU_ERF)
-                if sk_t > 1:
-                    self._gemm(plan, P(fht), w[o + "to.w"], P(parts_t), B * Lt, d, inter, bias=P(w[o + "to.b"]),
-                               residual=P(af) + toff * 4, a_rows=plain(inter), c_rows=plain(d), r_rows=trows, out_f32=True,
-                               split_k=sk_t, split_stride=B * Lt * d)
-                    self._ln_parts(plan, P(parts_t), sk_t, B * Lt * d, w[o + "to.g"], w[o + "to.bt"], P(hb) + toff * eb,
-                                   P(hf) + toff * 4, B * Lt, d, cfg.qf_ln_eps, out_rows=trows)
+        if run_vit:
+            # ---- ViT: patch-embed GEMM (+bias, + position table broadcast over the batch) ----
+            # step 0 (patchify) and the table pointer are bound at run time
+            xf32 = self.residual_dtype == torch.float32
+            rkw = dict(out_f32=xf32, res_bf16=not xf32)   # in-place residual-stream update
+            self._tag = "vit.patch_embed"
+            plan.patch_desc = self._gemm(plan, P(pa), w["patch.w"], P(x), M, D, Kp, bias=P(w["patch.b"]), residual=0,
+                                         a_rows=plain(Kp), c_rows=plain(D), r_rows=(D, N, 0), out_f32=xf32)
+            for i in range(cfg.run_depth):
+                o = f"vit.{i}."
+                fold = {}
+                if self.fold_ln:
+                    # vit.py:125 norm1 folded into attn.qkv: statistics of the residual stream, then the GEMM on x itself
+                    self._tag = "vit.ln_stats"
+                    if sk2 > 1 and i > 0:
+                        pass                             # the previous block's split-K tail (hk_residual_add_parts) left (mean, rstd)
+                    elif rpart is not None and i > 0:   # the previous block's fc2 epilogue left the row sums
+                        plan.steps.append((self.lib.hk_row_stats_finalize, (P(rpart), P(rstat), M, D // 64, cfg.vit_ln_eps),
+                                           "hk_row_stats_finalize", self._tag))
+                    else:
+                        plan.steps.append((self.lib.hk_row_stats, (P(x), P(rstat), M, D, cfg.vit_ln_eps), "hk_row_stats", self._tag))
+                    fold = dict(row_stats=P(rstat), col_c=P(w[o + "qkv.c"]))
                 else:
-                    self._gemm(plan, P(fht), w[o + "to.w"], P(tft), B * Lt, d, inter, bias=P(w[o + "to.b"]),
-                               residual=P(af) + toff * 4, a_rows=plain(inter), c_rows=plain(d), r_rows=trows, out_f32=True)
-                    self._ln(plan, P(tft), True, w[o + "to.g"], w[o + "to.bt"], P(hb) + toff * eb, P(hf) + toff * 4,
-                             B * Lt, d, cfg.qf_ln_eps, out_rows=trows)
-                # reads rows [nq:] of ab / af (complete at `fork`), writes rows [nq:] of hb / hf (read by the next
-                # layer's qkv GEMM, the step after `end`); the query branch touches rows [:nq] only
-                plan.side.append((fork, start, len(plan.steps)))
-        # llama_proj on the query rows (hawkeye_it.py:269)
-        self._tag = "llama_proj"
-        self._gemm(plan, P(hb), w["proj.w"], P(out), B * nq, cfg.llama_hidden, d, bias=P(w["proj.b"]),
-                   a_rows=qrows, c_rows=plain(cfg.llama_hidden), out_f32=True)
+                    self._tag = "vit.ln"
+                    self._ln(plan, P(x), xf32, w[o + "ln1.g"], w[o + "ln1.b"], P(xn), None, M, D, cfg.vit_ln_eps)
+                self._tag = "vit.qkv"
+                self._gemm(plan, P(x) if self.fold_ln else P(xn), w[o + "qkv.w"], P(qkv), M, 3 * D, D, bias=P(w[o + "qkv.b"]),
+                           a_rows=plain(D), c_rows=plain(3 * D), scale_cols=D, scale=qscale, **fold)
+                self._tag = "vit.attn"
+                self._attn(plan, P(qkv), P(qkv) + 2 * D, P(qkv) + 4 * D, P(att), B, Hv, N, N,
+                           3 * D, 3 * D, 3 * D, D, N * 3 * D, N * 3 * D, N * 3 * D, N * D)
+                self._tag = "vit.proj"
+                pkw = dict(row_part=P(rpart)) if rpart is not None else {}
+                self._gemm(plan, P(att), w[o + "proj.w"], P(x), M, D, D, bias=P(w[o + "proj.b"]), residual=P(x),
+                           a_rows=plain(D), c_rows=plain(D), r_rows=plain(D), **rkw, **pkw)
+                if self.fold_ln:
+                    self._tag = "vit.ln_stats"
+                    if rpart is not None:
+                        plan.steps.append((self.lib.hk_row_stats_finalize, (P(rpart), P(rstat), M, D // 64, cfg.vit_ln_eps),
+                                           "hk_row_stats_finalize", self._tag))
+                    else:
+                        plan.steps.append((self.lib.hk_row_stats, (P(x), P(rstat), M, D, cfg.vit_ln_eps), "hk_row_stats", self._tag))
+                    fold = dict(row_stats=P(rstat), col_c=P(w[o + "fc1.c"]))
+                else:
+                    self._tag = "vit.ln"
+                    self._ln(plan, P(x), xf32, w[o + "ln2.g"], w[o + "ln2.b"], P(xn), None, M, D, cfg.vit_ln_eps)
+                self._tag = "vit.fc1_gelu"
+                self._gemm(plan, P(x) if self.fold_ln else P(xn), w[o + "fc1.w"], P(hid), M, D * cfg.mlp_ratio, D,
+                           bias=P(w[o + "fc1.b"]), a_rows=plain(D), c_rows=plain(D * cfg.mlp_ratio),
+                           act=L.HK_ACT_GELU_ERF, **fold)
+                self._tag = "vit.fc2"
+                if i == cfg.run_depth - 1:
+                    pkw = {}                            # followed by vision_layernorm, which is not folded
+                if sk2 > 1:
+                    # small call: K split over workgroups, fp32 slices, then one pass that adds them into the residual
+                    # stream and leaves the next block's norm1 statistics (in place of hk_row_stats_finalize)
+                    self._gemm(plan, P(hid), w[o + "fc2.w"], P(parts_x), M, D, D * cfg.mlp_ratio, bias=P(w[o + "fc2.b"]),
+                               a_rows=plain(D * cfg.mlp_ratio), c_rows=plain(D), out_f32=True, split_k=sk2, split_stride=M * D)
+                    self._tag = "vit.fc2_tail"
+                    plan.steps.append((self.lib.hk_residual_add_parts,
+                                       (P(x), P(parts_x), sk2, M * D, P(rstat) if i < cfg.run_depth - 1 else None, M, D,
+                                        cfg.vit_ln_eps), "hk_residual_add_parts", self._tag))
+                else:
+                    self._gemm(plan, P(hid), w[o + "fc2.w"], P(x), M, D, D * cfg.mlp_ratio, bias=P(w[o + "fc2.b"]),
+                               residual=P(x), a_rows=plain(D * cfg.mlp_ratio), c_rows=plain(D), r_rows=plain(D), **rkw, **pkw)
+            # vision_layernorm (hawkeye_it.py:234) then the K/V projections of every cross layer at once
+            self._tag = "vision_layernorm"
+            self._ln(plan, P(x), xf32, w["vln.g"], w["vln.b"], P(xn), None, M, D, cfg.vision_ln_eps)
+        plan.vit_end = len(plan.steps)
+        if run_qf:
+            self._tag = "qformer.cross_kv"
+            self._gemm(plan, P(xn), w["ckv.w"], P(kvc), M, KVW, D, bias=P(w["ckv.b"]), a_rows=plain(D), c_rows=plain(KVW))
+
+            # ---- Q-Former ----
+            self._tag = "qformer"
+            plan.steps.append((self.lib.hk_qformer_embed_ln,
+                               (P(w["query"]), P(w["emb.word"]), P(w["emb.pos"]), P(ids) if Lt > 0 else None,
+                                P(w["emb.ln.g"]), P(w["emb.ln.b"]), P(hf), P(hb), B, nq, Lt, d, w["emb.word"].shape[0],
+                                cfg.qf_ln_eps), "hk_qformer_embed_ln", "qformer"))
+            qrows = (d, nq, S * d)
+            trows = (d, Lt, S * d)
+            eb = 2  # bytes per bf16
+            ci = 0
+            for i in range(cfg.qf_layers):
+                o = f"qf.{i}."
+                last = i == cfg.qf_layers - 1
+                self._gemm(plan, P(hb), w[o + "qkv.w"], P(qqkv), B * S, 3 * d, d, bias=P(w[o + "qkv.b"]),
+                           a_rows=plain(d), c_rows=plain(3 * d), scale_cols=d, scale=qscale)
+                self._attn(plan, P(qqkv), P(qqkv) + d * eb, P(qqkv) + 2 * d * eb, P(ctx), B, Hq, S, S,
+                           3 * d, 3 * d, 3 * d, d, S * 3 * d, S * 3 * d, S * 3 * d, S * d, key_bias=P(kbias))
+                self._gemm(plan, P(ctx), w[o + "ao.w"], P(tf), B * S, d, d, bias=P(w[o + "ao.b"]), residual=P(hf),
+                           a_rows=plain(d), c_rows=plain(d), r_rows=plain(d), out_f32=True)
+                self._ln(plan, P(tf), True, w[o + "ao.g"], w[o + "ao.bt"], P(ab), P(af), B * S, d, cfg.qf_ln_eps)
+                fork = len(plan.steps)
+                if i % cfg.cross_attention_freq == 0:
+                    self._gemm(plan, P(ab), w[o + "cq.w"], P(cq), B * nq, d, d, bias=P(w[o + "cq.b"]),
+                               a_rows=qrows, c_rows=plain(d), scale_cols=d, scale=qscale)
+                    self._attn(plan, P(cq), P(kvc) + ci * 2 * d * eb, P(kvc) + (ci * 2 + 1) * d * eb, P(cctx), B, Hq, nq, N,
+                               d, KVW, KVW, d, nq * d, N * KVW, N * KVW, nq * d)
+                    self._gemm(plan, P(cctx), w[o + "co.w"], P(tf), B * nq, d, d, bias=P(w[o + "co.b"]), residual=P(af),
+                               a_rows=plain(d), c_rows=plain(d), r_rows=qrows, out_f32=True)
+                    self._ln(plan, P(tf), True, w[o + "co.g"], w[o + "co.bt"], P(cb), P(cf), B * nq, d, cfg.qf_ln_eps)
+                    qin_b, qin_f, qin_rows = P(cb), P(cf), plain(d)
+                    ci += 1
+                else:
+                    qin_b, qin_f, qin_rows = P(ab), P(af), qrows
+                # query-branch FFN (Qformer.py:514-517) -> rows [:, :nq] of the next hidden state
+                self._gemm(plan, qin_b, w[o + "qi.w"], P(fh), B * nq, inter, d, bias=P(w[o + "qi.b"]),
+                           a_rows=qin_rows, c_rows=plain(inter), act=L.HK_ACT_GELU_ERF)
+                if sk_q > 1:
+                    self._gemm(plan, P(fh), w[o + "qo.w"], P(parts_q), B * nq, d, inter, bias=P(w[o + "qo.b"]), residual=qin_f,
+                               a_rows=plain(inter), c_rows=plain(d), r_rows=qin_rows, out_f32=True, split_k=sk_q,
+                               split_stride=B * nq * d)
+                    self._ln_parts(plan, P(parts_q), sk_q, B * nq * d, w[o + "qo.g"], w[o + "qo.bt"], P(hb), P(hf), B * nq, d,
+                                   cfg.qf_ln_eps, out_rows=qrows)
+                else:
+                    self._gemm(plan, P(fh), w[o + "qo.w"], P(tf), B * nq, d, inter, bias=P(w[o + "qo.b"]), residual=qin_f,
+                               a_rows=plain(inter), c_rows=plain(d), r_rows=qin_rows, out_f32=True)
+                    self._ln(plan, P(tf), True, w[o + "qo.g"], w[o + "qo.bt"], P(hb), P(hf), B * nq, d, cfg.qf_ln_eps,
+                             out_rows=qrows)
+                # text-branch FFN (Qformer.py:509-512); its last-layer result is never read (hawkeye_it.py:269)
+                if Lt > 0 and not last:
+                    toff = nq * d
+                    start = len(plan.steps)
+                    self._gemm(plan, P(ab) + toff * eb, w[o + "ti.w"], P(fht), B * Lt, inter, d, bias=P(w[o + "ti.b"]),
+                               a_rows=trows, c_rows=plain(inter), act=L.HK_ACT_GELU_ERF)
+                    if sk_t > 1:
+                        self._gemm(plan, P(fht), w[o + "to.w"], P(parts_t), B * Lt, d, inter, bias=P(w[o + "to.b"]),
+                                   residual=P(af) + toff * 4, a_rows=plain(inter), c_rows=plain(d), r_rows=trows, out_f32=True,
+                                   split_k=sk_t, split_stride=B * Lt * d)
+                        self._ln_parts(plan, P(parts_t), sk_t, B * Lt * d, w[o + "to.g"], w[o + "to.bt"], P(hb) + toff * eb,
+                                       P(hf) + toff * 4, B * Lt, d, cfg.qf_ln_eps, out_rows=trows)
+                    else:
+                        self._gemm(plan, P(fht), w[o + "to.w"], P(tft), B * Lt, d, inter, bias=P(w[o + "to.b"]),
+                                   residual=P(af) + toff * 4, a_rows=plain(inter), c_rows=plain(d), r_rows=trows, out_f32=True)
+                        self._ln(plan, P(tft), True, w[o + "to.g"], w[o + "to.bt"], P(hb) + toff * eb, P(hf) + toff * 4,
+                                 B * Lt, d, cfg.qf_ln_eps, out_rows=trows)
+                    # reads rows [nq:] of ab / af (complete at `fork`), writes rows [nq:] of hb / hf (read by the next
+                    # layer's qkv GEMM, the step after `end`); the query branch touches rows [:nq] only
+                    plan.side.append((fork, start, len(plan.steps)))
+            # llama_proj on the query rows (hawkeye_it.py:269)
+            self._tag = "llama_proj"
+            self._gemm(plan, P(hb), w["proj.w"], P(out), B * nq, cfg.llama_hidden, d, bias=P(w["proj.b"]),
+                       a_rows=qrows, c_rows=plain(cfg.llama_hidden), out_f32=True)
         return plan
 
     # ------------------------------------------------------------------ run
@@ -492,6 +505,9 @@ class HipEncoderEngine:
         device with norm = (mean3, std3), default the CLIP statistics of the eval scripts); input_ids/text_mask [B,Lt] int64 (or None);
         pos_embed fp32 [N,D] on the GPU (the table the caller's encoder holds for this T).
         Returns fp32 [B, n_query, llama_hidden] -- a view of the plan's output buffer."""
+        if self.halves != ("vit", "qformer"):
+            raise RuntimeError("forward() needs an engine that runs both halves; a two-device placement goes through "
+                               "forward_vit() on one engine and forward_qformer() on the other")
         plan, image, u8, B, T, Lt, H, W = self._prepare(image, input_ids, text_mask, pos_embed)
         cfg, ws, nq = self.cfg, plan.ws, self.cfg.n_query
         with torch.cuda.device(self.device):
@@ -528,6 +544,29 @@ class HipEncoderEngine:
         with torch.cuda.device(self.device):
             self._enqueue(plan, image, u8, norm, pos_embed, B, T, Lt, H, W, None, upto=plan.vit_end)
         return plan
+
+    @torch.no_grad()
+    def forward_qformer(self, image_embeds: torch.Tensor, input_ids, text_mask) -> torch.Tensor:
+        """The second half on its own (two-device placement, hawkeye_it.py:230-234: the ViT may sit on another GPU and
+        hands over image_embeds): image_embeds bf16 [B, N, D] = vision_layernorm's output, on any GPU -- copied into
+        this engine's plan -- then cross K/V, the Q-Former and llama_proj.  Returns fp32 [B, n_query, llama_hidden]."""
+        cfg = self.cfg
+        if "qformer" not in self.halves or not self.w:
+            raise RuntimeError("forward_qformer: this engine does not hold the Q-Former half (or has no weights yet)")
+        B, N, D = image_embeds.shape
+        Lp = cfg.patches_per_frame
+        if N % Lp != 0 or D != cfg.encoder_embed_dim or image_embeds.dtype != torch.bfloat16:
+            raise RuntimeError(f"image_embeds must be bf16 [B, T*{Lp}, {cfg.encoder_embed_dim}], got {tuple(image_embeds.shape)} {image_embeds.dtype}")
+        Lt = 0 if input_ids is None else int(input_ids.shape[1])
+        plan = self.plan_for(B, N // Lp, Lt)
+        self.calls += 1
+        with torch.cuda.device(self.device):
+            plan.ws["xn"].view(B, N, D).copy_(image_embeds, non_blocking=True)     # the device hop of hawkeye_it.py:234
+            if Lt > 0:
+                plan.ws["ids"].copy_(input_ids, non_blocking=True)
+                plan.ws["mask"].copy_(text_mask, non_blocking=True)
+            self._enqueue(plan, None, False, None, None, B, N // Lp, Lt, 0, 0, None, lo=plan.vit_end, no_input=True)
+        return plan.ws["out"].view(B, cfg.n_query, cfg.llama_hidden)
 
     def _prepare(self, image, input_ids, text_mask, pos_embed):
         """Input validation, plan lookup, copy of the token ids / mask into the plan."""
@@ -584,13 +623,17 @@ class HipEncoderEngine:
             self.plans.popitem(last=False)
         return plan
 
-    def _enqueue(self, plan, image, u8, norm, pos_embed, B, T, Lt, H, W, profile, upto=None):
-        """Every launch of one call, in order, on torch's current stream (also the body of the captured graph)."""
+    def _enqueue(self, plan, image, u8, norm, pos_embed, B, T, Lt, H, W, profile, upto=None, lo=0, no_input=False):
+        """Every launch of one call, in order, on torch's current stream (also the body of the captured graph).
+        lo / no_input: the launches from plan.steps[lo] on, without the patch gather (the Q-Former half of a two-device
+        placement starts from image_embeds already in plan.ws["xn"])."""
         cfg, ws = self.cfg, plan.ws
         stream = torch.cuda.current_stream().cuda_stream
         L.check(self.lib.hk_qformer_key_bias(ws["mask"].data_ptr() if Lt > 0 else None, ws["kbias"].data_ptr(), B,
                                              cfg.n_query, Lt, stream), "hk_qformer_key_bias")
-        if u8:
+        if no_input:
+            pass
+        elif u8:
             mean, std = norm if norm is not None else (ops.CLIP_MEAN, ops.CLIP_STD)
             m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
             L.check(self.lib.hk_patchify_u8(image.data_ptr(), ws["patches"].data_ptr(), B, T, H, W, cfg.patch_size,
@@ -598,7 +641,8 @@ class HipEncoderEngine:
         else:
             L.check(self.lib.hk_patchify_bf16(image.data_ptr(), ws["patches"].data_ptr(), B, T, H, W,
                                               cfg.patch_size, stream), "hk_patchify_bf16")
-        plan.patch_desc.residual = pos_embed.data_ptr()
+        if not no_input:
+            plan.patch_desc.residual = pos_embed.data_ptr()
         if profile is None and upto is None and self.side_stream and plan.side:
             # text-branch segments on the side stream: fork event recorded on the main stream at the fork point, the
             # segment waits for it, the main stream waits for the segment's end event before the step that follows it
@@ -613,6 +657,8 @@ class HipEncoderEngine:
             ends = {e: k for k, (_, _, e) in enumerate(plan.side)}
             cur = None
             for idx, (fn, args, name, _) in enumerate(plan.steps):
+                if idx < lo:
+                    continue
                 if idx in ends:
                     k = ends[idx]
                     plan.side_events[2 * k + 1].record(side)
@@ -627,7 +673,7 @@ class HipEncoderEngine:
                 if rc != 0:
                     L.check(rc, name)
         elif profile is None:
-            for fn, args, name, _ in plan.steps[:upto]:
+            for fn, args, name, _ in plan.steps[lo:upto]:
                 rc = fn(*args, stream)
                 if rc != 0:
                     L.check(rc, name)

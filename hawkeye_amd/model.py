@@ -248,6 +248,8 @@ class HawkEyeEncoder(nn.Module):
         self.out_dtype = out_dtype        # the reference returns fp16 under its autocast (blip2.py:42)
         self.devices = [torch.device("cuda", 0), torch.device("cuda", 0)]
         self._engine: Optional[HipEncoderEngine] = None
+        self._vit_engine: Optional[HipEncoderEngine] = None    # two-device placement only (set_device_ids([a, b]))
+        self._force_split = False       # tests: run the two-engine path with both engines on ONE device
         self._engine_key = {"vit": None, "qformer": None}
         self._train_engine: Optional[QFormerTrainEngine] = None
         self._overlap = None      # (average, bucket_mb) once enable_overlapped_grad_reduce() was called
@@ -281,13 +283,44 @@ class HawkEyeEncoder(nn.Module):
         return list(self.parameters())[0].device
 
     def set_device_ids(self, device_ids):           # hawkeye_it.py:197-211
+        """One id: everything on that GPU.  Two ids: the reference's optional split -- vision_encoder +
+        vision_layernorm on devices[1], Q-Former / query tokens / llama_proj on devices[0]; encode_img then runs the
+        ViT half on devices[1] and hands image_embeds (bf16 [B, N, 1024]) over to devices[0] (hawkeye_it.py:230-234).
+        A 288 GB MI355X never needs it; it is there because the reference's trainer exposes it (model_parallel,
+        tasks/shared_utils.py:48-51).  Inference only: the training path keeps both halves on one device."""
         assert isinstance(device_ids, list) and 1 <= len(device_ids) <= 2
         if len(device_ids) == 1:
             device_ids = [device_ids[0], device_ids[0]]
-        if device_ids[0] != device_ids[1]:
-            raise NotImplementedError("two-device ViT placement is not needed on a 288 GB MI355X; use one device id")
         self.devices = [torch.device("cuda", i) if isinstance(i, int) else torch.device(i) for i in device_ids]
         self.to(self.devices[0])
+        if self.devices[1] != self.devices[0]:
+            self.vision_encoder.to(self.devices[1])
+            self.vision_layernorm.to(self.devices[1])
+        self._engine = self._vit_engine = None
+        self._engine_key = {"vit": None, "qformer": None}
+        self._train_engine = None
+
+    def _split_placement(self) -> bool:
+        return self._force_split or next(self.vision_layernorm.parameters()).device != self.device
+
+    def _sync_split_engines(self):
+        """Two engines, one per half, each on the device its parameters live on."""
+        dq = self.device
+        dv = next(self.vision_layernorm.parameters()).device
+        if dq.type != "cuda" or dv.type != "cuda":
+            raise RuntimeError("HawkEyeEncoder.encode_img needs both halves on MI355X devices; there is no CPU path "
+                               "(low_resource / vit_to_cpu of the reference are not offered)")
+        if (self._engine is None or self._engine.device != dq or self._engine.halves != ("qformer",)
+                or self._vit_engine is None or self._vit_engine.device != dv):
+            self._engine = HipEncoderEngine(self.cfg, dq, self.residual_dtype, halves=("qformer",))
+            self._vit_engine = HipEncoderEngine(self.cfg, dv, self.residual_dtype, halves=("vit",))
+            self._engine_key = {"vit": None, "qformer": None}
+        for part, eng in (("vit", self._vit_engine), ("qformer", self._engine)):
+            key = (str(eng.device), self._weights_key(part))
+            if self._engine_key[part] != key:
+                eng.load_state_dict(self.state_dict(), parts=(part,))
+                self._engine_key[part] = key
+        return self._vit_engine, self._engine
 
     @classmethod
     def from_reference_config(cls, config, **kw):
@@ -319,7 +352,7 @@ class HawkEyeEncoder(nn.Module):
         if dev.type != "cuda":
             raise RuntimeError("HawkEyeEncoder.encode_img needs the model on an MI355X (model.to('cuda')); "
                                "there is no CPU path")
-        if self._engine is None or self._engine.device != dev:
+        if self._engine is None or self._engine.device != dev or self._engine.halves != ("vit", "qformer"):
             self._engine = HipEncoderEngine(self.cfg, dev, self.residual_dtype)
             self._engine_key = {"vit": None, "qformer": None}
             self._train_engine = None
@@ -455,12 +488,44 @@ class HawkEyeEncoder(nn.Module):
             raise RuntimeError(f"encode_frames expects uint8 frames, got {frames.dtype}")
         return self._encode(frames, instruction, (tuple(mean), tuple(std)))
 
+    def _encode_split(self, image, instruction, norm):
+        """hawkeye_it.py:226-269 with the ViT on devices[1]: image -> devices[1], ViT + vision_layernorm there,
+        image_embeds -> devices[0] (:234), Q-Former + llama_proj there, result back on image.device."""
+        device = image.device
+        ev, eq = self._sync_split_engines()
+        B, T = image.shape[0], image.shape[1]
+        use_image = True if T == 1 else False
+        table = self._table(use_image, T * self.cfg.patches_per_frame, ev.device)
+        ids = mask = None
+        if self.qformer_text_input:
+            ids, mask = self._tokenize(instruction, B, eq.device)
+        with torch.no_grad():
+            plan = ev.forward_vit(image.to(ev.device), None, None, table, norm=norm)        # :230-231
+            N = T * self.cfg.patches_per_frame
+            embeds = plan.ws["xn"].view(B, N, self.cfg.encoder_embed_dim)
+            if eq.device != ev.device:
+                # the consumer's stream must not start the copy before the producer's stream has written xn
+                done = torch.cuda.Event()
+                done.record(torch.cuda.current_stream(ev.device))
+                torch.cuda.current_stream(eq.device).wait_event(done)
+            out = eq.forward_qformer(embeds, ids, mask)
+            out = out.to(self.out_dtype) if self.out_dtype != torch.float32 else out.clone()
+        return out.to(device), use_image
+
     def _encode(self, image, instruction, norm):
         device = image.device
         dropout = self.qformer.training
         need_grad = torch.is_grad_enabled() and any(
             p.requires_grad for n, p in self.named_parameters() if not n.startswith(("vision_encoder.", "vision_layernorm.")))
         train_path = dropout or need_grad
+        if self.low_resource:
+            raise NotImplementedError("low_resource (ViT in fp32 on the CPU, hawkeye_it.py:213-223) is not offered: the "
+                                      "path has no CPU arithmetic; a 288 GB MI355X holds the 0.6 GB of ViT operands")
+        if self._split_placement():
+            if train_path:
+                raise NotImplementedError("two-device placement is inference only; put the model on one device to train "
+                                          "(model.eval() and torch.no_grad() select the inference path)")
+            return self._encode_split(image, instruction, norm)
         eng = self.sync_engine(parts=("vit",) if train_path else ("vit", "qformer"))
         if device != eng.device:
             image = image.to(eng.device)

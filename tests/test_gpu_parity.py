@@ -101,6 +101,34 @@ def test_full_size_goldens(golden_dir, name):
     _check(f"{name}.{stage}.query_rows", got, g[f"digest.{stage}.slice"][keep])
 
 
+@pytest.mark.parametrize("depth", [1, 2, 7])
+def test_intermediate_qformer_layers_against_the_golden_digests(golden_dir, depth):
+    """The fixtures hold a digest of EVERY Q-Former layer's output (qf_layer_0..11).  Layer k's output of the
+    12-layer model is the last hidden state of the same weights cut to k + 1 layers, so a model built with
+    qf_layers = depth exposes it (query rows: the text rows of a last layer are never computed on this path)."""
+    from dataclasses import replace
+    g = np.load(os.path.join(golden_dir, "full_T8_B1.npz"))
+    B, T, seed = int(g["B"]), int(g["T"]), int(g["seed"])
+    cfg = replace(FULL, qf_layers=depth)
+    m = HawkEyeEncoder(cfg, out_dtype=torch.float32)
+    sd = W.make_state_dict(FULL, seed)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not missing and all(".encoder.layer." in k for k in unexpected)       # the layers past `depth`
+    m = m.to(DEV).eval()
+    m.vision_encoder.encoder.pos_embed = posembed.video_pos_embed(T, FULL.patches_per_frame, FULL.encoder_embed_dim,
+                                                                  FULL.ckpt_num_frame)
+    image = W.make_clip(B, T, FULL.img_size, seed).to(DEV)
+    ids, mask = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["text_mask"])
+    m.encode_img(image, (ids, mask))
+    S = 96 + ids.shape[1]
+    stage = f"qf_layer_{depth - 1}"
+    rows = g[f"digest.{stage}.rows"]
+    keep = np.nonzero(rows % S < 96)[0]
+    cols = torch.from_numpy(g[f"digest.{stage}.cols"]).to(DEV)
+    hf = m._engine.plans[(B, T, ids.shape[1])].ws["hf"]
+    _check(f"{stage}.query_rows", hf[torch.from_numpy(rows[keep]).to(DEV)][:, cols], g[f"digest.{stage}.slice"][keep])
+
+
 def test_no_text_branch_matches_reference(golden_dir):
     """qformer_text_input=False (hawkeye_it.py:65-70, 261-267): the Q-Former sees the 96 query rows only (Lt = 0);
     golden from the reference modules called without input_ids."""
@@ -374,6 +402,37 @@ def test_packed_operand_file_round_trip(tmp_path):
     other = HawkEyeEncoder(FULL).to(DEV)
     with pytest.raises(RuntimeError, match="different EncoderConfig"):
         CK.load_packed(other, path)
+
+
+def test_two_device_placement_path_equals_single_engine():
+    """set_device_ids([a, b]) (hawkeye_it.py:197-211): ViT half on one engine, image_embeds handed over, Q-Former half
+    on another.  The box has one GPU, so the two engines are forced onto the same device: same launches, same bits as
+    the single engine; set_device_ids itself is checked for the one-device forms and for its bookkeeping."""
+    cfg, seed, B, T = SMALL, 37, 3, 2
+    m = _model(cfg, seed, T)
+    image = W.make_clip(B, T, cfg.img_size, seed).to(DEV)
+    ids, mask = W.make_instruction_ids(B, 5, cfg.qf_vocab, seed, ragged=True)
+    want, _ = m.encode_img(image, (ids, mask))
+    want = want.clone()
+    m._force_split = True
+    got, use_image = m.encode_img(image, (ids, mask))
+    assert m._vit_engine is not None and m._vit_engine.halves == ("vit",) and m._engine.halves == ("qformer",)
+    assert "x" not in m._engine.pool.bufs and "hf" not in m._vit_engine.pool.bufs     # each engine holds its half only
+    assert "vit.0.qkv.w" not in m._engine.w and "ckv.w" not in m._vit_engine.w
+    assert not use_image and torch.equal(got, want)
+    frames = torch.randint(0, 256, (B, T, cfg.img_size, cfg.img_size, 3), dtype=torch.uint8, device=DEV)
+    a, _ = m.encode_frames(frames, (ids, mask))
+    m._force_split = False
+    b, _ = m.encode_frames(frames, (ids, mask))
+    assert m._engine.halves == ("vit", "qformer") and torch.equal(a, b)
+    m.set_device_ids([0])
+    assert m.devices == [torch.device("cuda", 0)] * 2 and not m._split_placement()
+    m.set_device_ids(["cuda:0", "cuda:0"])
+    c, _ = m.encode_img(image, (ids, mask))
+    assert torch.equal(c, want)
+    m.low_resource = True
+    with pytest.raises(NotImplementedError, match="low_resource"):
+        m.encode_img(image, (ids, mask))
 
 
 def test_default_output_dtype_and_errors():
