@@ -36,6 +36,10 @@ struct AttnParams {
     int prio;     // staged wave priority inside a tile (see the kernel); 0 = off (A/B aid)
     int o_vec16;  // O rows 16-byte aligned: the epilogue may store whole 128-byte row segments
     unsigned long long* stamp;  // diagnostic build (-DHK_ATTN_STAMP) only: per-wave phase cycle totals
+    // key split (small calls): the grid's batch index is b * splits + s; slice s covers keys [s * chunk, ...), writes its
+    // normalised partial output to O (= the partial buffer, batch index b * splits + s) and the row's log2-sum-exp to lse
+    int splits, chunk;
+    float* lse;
 };
 
 constexpr int QB = 128;   // query rows per workgroup
@@ -66,7 +70,10 @@ __device__ __forceinline__ float half_swap_sum(float x) {
     return a + b;
 }
 
-template <bool HAS_BIAS, int MODE, int OCC, int LOADER>
+// SPLIT: the key-split form (small calls) is an instantiation of its own -- its extra live scalars (slice base
+// pointers, slice length, lse pointer) cost the production instantiation SGPR spills and 20 bytes of scratch when
+// they shared one body.
+template <bool HAS_BIAS, int MODE, int OCC, int LOADER, bool SPLIT = false>
 __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KT * 128];  // [stage][K|V][64 keys][128 B]
 
@@ -85,9 +92,23 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
     }
     const int bh = lid / p.nqb;
     const int qb = lid - bh * p.nqb;
-    const int b = bh / p.H;
+    int b = bh / p.H;
     const int head = bh - b * p.H;
     const int q0 = qb * QB + wave * 32;
+    const int bo = b;          // batch index of the output (the partial buffer's when the keys are split)
+    // this workgroup's keys: all of them, or one slice (scalars, not a modified copy of the argument block: that
+    // copy lands in scratch)
+    const __bf16* Kp = p.K;
+    const __bf16* Vp = p.V;
+    int Nk = p.Nk;
+    if (SPLIT && p.splits > 1) {
+        const int sl = b % p.splits;
+        b /= p.splits;
+        const int k0 = sl * p.chunk;
+        Kp += (int64_t)k0 * p.ldk;
+        Vp += (int64_t)k0 * p.ldv;
+        Nk = min(p.chunk, p.Nk - k0);
+    }
 
     // ---- Q fragments: B operand, lane (r, h) holds Q[q0 + r][16 ks + 8 h .. +8] ----
     bf16x8 qf[4];
@@ -99,8 +120,8 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
     }
 
     // ---- K/V tile loader: 256 threads x 16 B x 2 passes per operand ----
-    const __bf16* kbase = p.K + (int64_t)b * p.bsk + head * 64 + (tid & 7) * 8;
-    const __bf16* vbase = p.V + (int64_t)b * p.bsv + head * 64 + (tid & 7) * 8;
+    const __bf16* kbase = Kp + (int64_t)b * p.bsk + head * 64 + (tid & 7) * 8;
+    const __bf16* vbase = Vp + (int64_t)b * p.bsv + head * 64 + (tid & 7) * 8;
     const int lkey = tid >> 3;  // 0..31 (+32 on the second pass)
     int kst[2], vst[2];         // LDS byte offsets of this thread's two chunks
 #pragma unroll
@@ -114,7 +135,7 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
     const __bf16* vp_ = vbase + (int64_t)lkey * p.ldv;
     const int64_t k32 = 32 * p.ldk, v32 = 32 * p.ldv;
     auto gload = [&](int tile) __attribute__((always_inline)) {
-        if ((tile + 1) * KT <= p.Nk) {
+        if ((tile + 1) * KT <= Nk) {
             kr[0] = *reinterpret_cast<const bf16x8*>(kp);
             kr[1] = *reinterpret_cast<const bf16x8*>(kp + k32);
             vr[0] = *reinterpret_cast<const bf16x8*>(vp_);
@@ -122,7 +143,7 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
         } else {  // ragged last tile: clamp to the last key (masked to -inf below)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int key = min(tile * KT + i * 32 + lkey, p.Nk - 1);
+                const int key = min(tile * KT + i * 32 + lkey, Nk - 1);
                 kr[i] = *reinterpret_cast<const bf16x8*>(kbase + (int64_t)key * p.ldk);
                 vr[i] = *reinterpret_cast<const bf16x8*>(vbase + (int64_t)key * p.ldv);
             }
@@ -144,15 +165,15 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
     const int ck = (tid & 7) ^ ((lkey >> 1) & 7);
     const int cv = (tid & 7) ^ (((lkey >> 1) & 1) << 2);
     // address = wave-uniform base (advanced per tile on the scalar unit) + a constant 32-bit per-lane byte offset
-    const char* kU = reinterpret_cast<const char*>(p.K + (int64_t)b * p.bsk + head * 64);
-    const char* vU = reinterpret_cast<const char*>(p.V + (int64_t)b * p.bsv + head * 64);
+    const char* kU = reinterpret_cast<const char*>(Kp + (int64_t)b * p.bsk + head * 64);
+    const char* vU = reinterpret_cast<const char*>(Vp + (int64_t)b * p.bsv + head * 64);
     const uint32_t klane = (uint32_t)(((int64_t)lkey * p.ldk + ck * 8) * 2);
     const uint32_t vlane = (uint32_t)(((int64_t)lkey * p.ldv + cv * 8) * 2);
     const int64_t k32b = 64 * p.ldk, v32b = 64 * p.ldv;  // 32 key rows, in bytes
     auto gdma = [&](int tile, int stage) __attribute__((always_inline)) {
         char* ks = smem + stage * (2 * KT * 128) + wave * 8 * 128;
         char* vs = ks + KT * 128;
-        if ((tile + 1) * KT <= p.Nk) {
+        if ((tile + 1) * KT <= Nk) {
             const char* kt_ = kU + (int64_t)tile * 2 * k32b;
             const char* vt_ = vU + (int64_t)tile * 2 * v32b;
             if constexpr (HAS_BIAS) {   // that instantiation is short of SGPRs: the builtin (vector address) form throughout
@@ -169,9 +190,9 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
         } else {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int key = min(tile * KT + i * 32 + lkey, p.Nk - 1);
-                const __bf16* ka = p.K + (int64_t)b * p.bsk + head * 64 + ck * 8 + (int64_t)key * p.ldk;
-                const __bf16* va = p.V + (int64_t)b * p.bsv + head * 64 + cv * 8 + (int64_t)key * p.ldv;
+                const int key = min(tile * KT + i * 32 + lkey, Nk - 1);
+                const __bf16* ka = Kp + (int64_t)b * p.bsk + head * 64 + ck * 8 + (int64_t)key * p.ldk;
+                const __bf16* va = Vp + (int64_t)b * p.bsv + head * 64 + cv * 8 + (int64_t)key * p.ldv;
                 if constexpr (HAS_BIAS) {
                     glds16(ka, ks + i * 32 * 128);
                     glds16(va, vs + i * 32 * 128);
@@ -221,7 +242,7 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
     };
     if (LOADER == 2) set_cneg();
 
-    const int NT = (p.Nk + KT - 1) / KT;
+    const int NT = (Nk + KT - 1) / KT;
     bool bad = false;   // MODE 2, first pass: some score left the range the no-maximum form covers
 
     // One K/V tile.  FIRST (tile 0) and RAGGED (last tile when Nk % 64 != 0) are compile-time so the
@@ -290,7 +311,7 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
             if (p.prio) __builtin_amdgcn_s_setprio(0);
             // register i of st[kt] <-> key t*64 + 32 kt + (i & 3) + 8 (i >> 2) + 4 h
             if (HAS_BIAS) {
-                const float* kb = p.key_bias + (int64_t)b * p.Nk;
+                const float* kb = p.key_bias + (int64_t)b * Nk;
                 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
@@ -304,7 +325,7 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
                         } else {
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
-                                if (key0 + e < p.Nk) st[kt][4 * g + e] = __builtin_fmaf(kb[key0 + e], HK_LOG2E, st[kt][4 * g + e]);
+                                if (key0 + e < Nk) st[kt][4 * g + e] = __builtin_fmaf(kb[key0 + e], HK_LOG2E, st[kt][4 * g + e]);
                         }
                     }
             }
@@ -314,7 +335,7 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         const int key = t * KT + 32 * kt + (i & 3) + 8 * (i >> 2) + 4 * h;
-                        if (key >= p.Nk) st[kt][i] = NEG_BIG;
+                        if (key >= Nk) st[kt][i] = NEG_BIG;
                     }
             }
         };
@@ -422,7 +443,7 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
     using F_ = std::false_type;
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
-    const bool ragged = (p.Nk % KT) != 0;
+    const bool ragged = (Nk % KT) != 0;
     auto run_pass = [&](auto mode_c) __attribute__((always_inline)) {
         if (LOADER >= 1) {
             gdma(0, 0);
@@ -478,6 +499,8 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
 
     // ---- normalise and store: lane (r, h) holds O[q0 + r][32 dt + 8 g + 4 h .. +4] ----
     const float inv = 1.0f / l_tot;
+    if (SPLIT && p.lse != nullptr && h == 0 && q0 + r < p.Nq)   // key split: the slice's weight in the combine
+        p.lse[((int64_t)bo * p.H + head) * p.Nq + q0 + r] = m_run + __builtin_amdgcn_logf(l_tot);
     if (p.o_vec16) {
         // Whole 128-byte row segments: the wave's 32 x 64 bf16 block is transposed through its own 4 KB of the
         // (now idle -- every tile ends in a workgroup barrier) K/V staging area, 16-B chunk c of row r at chunk
@@ -493,7 +516,7 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
                 o[1] = pack_bf16x2(ot[dt][4 * g + 2] * inv, ot[dt][4 * g + 3] * inv);
                 *reinterpret_cast<u32x2*>(stg + r * 128 + (((4 * dt + g) ^ sw) << 4) + 8 * h) = o;
             }
-        __bf16* ob = p.O + (int64_t)b * p.bso + head * 64 + (lane & 7) * 8;
+        __bf16* ob = p.O + (int64_t)bo * p.bso + head * 64 + (lane & 7) * 8;
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int row = it * 8 + (lane >> 3);
@@ -504,7 +527,7 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
     }
     const int qrow = q0 + r;
     if (qrow < p.Nq) {
-        __bf16* op = p.O + (int64_t)b * p.bso + (int64_t)qrow * p.ldo + head * 64 + 4 * h;
+        __bf16* op = p.O + (int64_t)bo * p.bso + (int64_t)qrow * p.ldo + head * 64 + 4 * h;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -517,6 +540,40 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
     }
 }
 
+
+// Combine of a key-split launch: O[b][q][h][:] = sum_s w_s * part[b * S + s][q][h][:] / sum_s w_s, w_s = 2^(lse_s - max lse).
+// One thread per 8 head dims (16 bytes); slices in index order (bit-reproducible).
+__global__ __launch_bounds__(256) void hk_attn_combine_kernel(const __bf16* part, const float* lse, __bf16* O, int S, int B,
+                                                             int H, int Nq, int64_t ldo, int64_t bso) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int c = (int)(idx & 7);
+    int64_t rest = idx >> 3;
+    const int h = (int)(rest % H);
+    rest /= H;
+    const int q = (int)(rest % Nq);
+    const int b = (int)(rest / Nq);
+    if (b >= B) return;
+    float m = -3.0e38f;
+    for (int s = 0; s < S; ++s) m = fmaxf(m, lse[(((int64_t)b * S + s) * H + h) * Nq + q]);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float den = 0.f;
+    for (int s = 0; s < S; ++s) {
+        const int64_t bp = (int64_t)b * S + s;
+        const float w = __builtin_amdgcn_exp2f(lse[(bp * H + h) * Nq + q] - m);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(part + ((bp * Nq + q) * H + h) * 64 + c * 8);
+        den += w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[2 * e] = __builtin_fmaf(w, bf16_lo(v[e]), acc[2 * e]);
+            acc[2 * e + 1] = __builtin_fmaf(w, bf16_hi(v[e]), acc[2 * e + 1]);
+        }
+    }
+    const float inv = 1.0f / den;
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(acc[2 * e] * inv, acc[2 * e + 1] * inv);
+    *reinterpret_cast<u32x4*>(O + (int64_t)b * bso + (int64_t)q * ldo + h * 64 + c * 8) = o;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Software-pipelined variant for the ViT shape (no key bias): one loop iteration runs the softmax and P.V of tile t
@@ -949,6 +1006,25 @@ extern "C" int hk_flash_attn_bf16(const hk_attn_desc* d, void* stream) {
     p.bsv = d->bsv;
     p.bso = d->bso;
     p.nqb = (d->Nq + QB - 1) / QB;
+    p.splits = 1;
+    p.chunk = 0;
+    p.lse = nullptr;
+    int nsplit = 1;
+    if (d->key_splits > 1) {
+        HK_REQUIRE(d->key_bias == nullptr && d->o_part != nullptr && d->lse_part != nullptr && d->key_splits <= 64 &&
+                       (uintptr_t)d->o_part % 16 == 0 && (uintptr_t)d->lse_part % 4 == 0 && d->ldo % 8 == 0 && d->bso % 8 == 0,
+                   "hk_flash_attn_bf16: key_splits needs no key_bias, o_part / lse_part buffers and 16-byte aligned O rows");
+        const int chunk = ((d->Nk + d->key_splits - 1) / d->key_splits + KT - 1) / KT * KT;   // whole tiles per slice
+        nsplit = (d->Nk + chunk - 1) / chunk;                                                   // no empty slice
+        if (nsplit > 1) {
+            p.splits = nsplit;
+            p.chunk = chunk;
+            p.lse = d->lse_part;
+            p.O = reinterpret_cast<__bf16*>(d->o_part);     // [B * nsplit][Nq][H * 64]
+            p.ldo = (int64_t)d->H * 64;
+            p.bso = (int64_t)d->Nq * d->H * 64;
+        }
+    }
     static const int prio = getenv("HK_ATTN_PRIO") ? atoi(getenv("HK_ATTN_PRIO")) : 1;
     p.prio = prio;
     p.stamp = nullptr;
@@ -957,8 +1033,8 @@ extern "C" int hk_flash_attn_bf16(const hk_attn_desc* d, void* stream) {
 #endif
     // HK_ATTN_EPI=0: A/B aid, per-lane 8-byte stores everywhere
     static const int epi = getenv("HK_ATTN_EPI") ? atoi(getenv("HK_ATTN_EPI")) : 1;
-    p.o_vec16 = (epi != 0 && d->ldo % 8 == 0 && d->bso % 8 == 0) ? 1 : 0;
-    const long nwg = (long)p.nqb * d->H * d->B;
+    p.o_vec16 = (epi != 0 && p.ldo % 8 == 0 && p.bso % 8 == 0) ? 1 : 0;
+    const long nwg = (long)p.nqb * d->H * d->B * nsplit;
     HK_REQUIRE(nwg < (1L << 31), "hk_flash_attn_bf16: grid too large");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     // HK_ATTN_MODE: softmax variant; HK_ATTN_OCC: waves per SIMD the register allocation targets;
@@ -974,7 +1050,7 @@ extern "C" int hk_flash_attn_bf16(const hk_attn_desc* d, void* stream) {
     // per-tile kernel.  Measured on one device, B=32 N=3136: per-tile 1356 us, pipelined 1457 (4 waves) / 1505 (8 waves):
     // the loop is bound by vector issue slots per tile, not by latency, so overlapping a wave's own phases buys nothing.
     static const int pipe = getenv("HK_ATTN_PIPE") ? atoi(getenv("HK_ATTN_PIPE")) : 0;
-    if (!d->key_bias && (pipe == 2 || pipe == 8)) {
+    if (!d->key_bias && nsplit == 1 && (pipe == 2 || pipe == 8)) {
         const int nw = pipe == 8 ? 8 : 4;
         p.nqb = (d->Nq + nw * 32 - 1) / (nw * 32);
         const dim3 g2((unsigned)((long)p.nqb * d->H * d->B)), b2(nw * 64);
@@ -983,6 +1059,7 @@ extern "C" int hk_flash_attn_bf16(const hk_attn_desc* d, void* stream) {
         else if (prio == 0) hipLaunchKernelGGL((hk_attn_pipe_kernel<8, 0>), g2, b2, 0, s, p);
         else hipLaunchKernelGGL((hk_attn_pipe_kernel<8, 1>), g2, b2, 0, s, p);
     }
+    else if (nsplit > 1) hipLaunchKernelGGL((hk_attn_kernel<false, 1, 3, 1, true>), grid, block, 0, s, p);
     else if (d->key_bias && bvar == 0) HK_ATTN_LAUNCH(true, 0, 1, 0);
     else if (d->key_bias) HK_ATTN_LAUNCH(true, 1, 2, 1);
     else if (mode == 2 && occ == 3) HK_ATTN_LAUNCH(false, 2, 3, 1);
@@ -998,5 +1075,12 @@ extern "C" int hk_flash_attn_bf16(const hk_attn_desc* d, void* stream) {
     else HK_ATTN_LAUNCH(false, 0, 2, 0);
 #undef HK_ATTN_LAUNCH
     HK_CHECK_LAUNCH("hk_flash_attn_bf16");
+    if (nsplit > 1) {
+        const long nthr = (long)d->B * d->Nq * d->H * 8;
+        hipLaunchKernelGGL(hk_attn_combine_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s,
+                           reinterpret_cast<const __bf16*>(d->o_part), d->lse_part, reinterpret_cast<__bf16*>(d->O), nsplit,
+                           d->B, d->H, d->Nq, d->ldo, d->bso);
+        HK_CHECK_LAUNCH("hk_flash_attn_bf16(combine)");
+    }
     return HK_OK;
 }

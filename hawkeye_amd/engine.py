@@ -235,6 +235,19 @@ class HipEncoderEngine:
         plan.steps.append((self.lib.hk_gemm_bf16, (C.byref(d),), "hk_gemm_bf16", self._tag))
         return d
 
+    @staticmethod
+    def key_splits_for(B: int, H: int, Nq: int, Nk: int) -> int:
+        """Key-split factor of a cross-attention launch (hk_attn_desc.key_splits): 1 unless the launch is a handful of
+        workgroups each walking every key in turn (B = 1: 12 workgroups x 37 tiles).  Isolated, B = 1 (tools/
+        attn_split_bench.py): T = 12 28.2 -> 17.3 us, T = 16 36.4 -> 17.4 us at 4 slices (two launches: the floor);
+        the ViT's self-attention (304 workgroups at B = 1) gains nothing (38.9 -> 35.9 us at 2 slices, T = 16 slower)
+        and stays unsplit."""
+        if os.environ.get("HK_ATTN_SPLIT", "1") == "0":
+            return 1
+        wgs = B * H * -(-Nq // 128)
+        s = min(4, 128 // max(wgs, 1), Nk // 256)
+        return s if s >= 2 else 1
+
     def _attn(self, plan, *a, **kw):
         d = ops.attn_desc(*a, **kw)
         plan.keep.append(d)
@@ -352,6 +365,11 @@ class HipEncoderEngine:
         qscale = (64 ** -0.5) * LOG2E
 
         if run_vit:
+            ksv = 1      # the ViT's self-attention is never split (see key_splits_for)
+            akw = {}
+            if ksv > 1:
+                akw = dict(key_splits=ksv, o_part=P(plan.buf("attn_part", (B * ksv, N, D), bf16, dev)),
+                           lse_part=P(plan.buf("attn_lse", (B * ksv, Hv, N), f32, dev)))
             # ---- ViT: patch-embed GEMM (+bias, + position table broadcast over the batch) ----
             # step 0 (patchify) and the table pointer are bound at run time
             xf32 = self.residual_dtype == torch.float32
@@ -421,6 +439,11 @@ class HipEncoderEngine:
             self._ln(plan, P(x), xf32, w["vln.g"], w["vln.b"], P(xn), None, M, D, cfg.vision_ln_eps)
         plan.vit_end = len(plan.steps)
         if run_qf:
+            ksc = self.key_splits_for(B, Hq, nq, N)
+            ckw = {}
+            if ksc > 1:
+                ckw = dict(key_splits=ksc, o_part=P(plan.buf("cattn_part", (B * ksc, nq, d), bf16, dev)),
+                           lse_part=P(plan.buf("cattn_lse", (B * ksc, Hq, nq), f32, dev)))
             self._tag = "qformer.cross_kv"
             self._gemm(plan, P(xn), w["ckv.w"], P(kvc), M, KVW, D, bias=P(w["ckv.b"]), a_rows=plain(D), c_rows=plain(KVW))
 

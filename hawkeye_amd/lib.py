@@ -43,6 +43,7 @@ class HkAttnDesc(C.Structure):
         ("ldq", C.c_int64), ("ldk", C.c_int64), ("ldv", C.c_int64), ("ldo", C.c_int64),
         ("bsq", C.c_int64), ("bsk", C.c_int64), ("bsv", C.c_int64), ("bso", C.c_int64),
         ("head_dim", C.c_int32), ("causal", C.c_int32),
+        ("key_splits", C.c_int32), ("o_part", C.c_void_p), ("lse_part", C.c_void_p),
     ]
 
 

@@ -142,8 +142,9 @@ def fold_layernorm(weight: torch.Tensor, bias: Optional[torch.Tensor], gamma: to
 
 
 def attn_desc(Q, K, V, O, B, H, Nq, Nk, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, key_bias=None, head_dim=0,
-              causal=False) -> L.HkAttnDesc:
+              causal=False, key_splits=0, o_part=None, lse_part=None) -> L.HkAttnDesc:
     d = L.HkAttnDesc()
+    d.key_splits, d.o_part, d.lse_part = key_splits, o_part, lse_part
     d.head_dim, d.causal = head_dim, 1 if causal else 0
     d.Q, d.K, d.V, d.O, d.key_bias = Q, K, V, O, key_bias
     d.B, d.H, d.Nq, d.Nk = B, H, Nq, Nk
@@ -157,10 +158,10 @@ def run_attn(d: L.HkAttnDesc):
 
 
 def flash_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, key_bias: Optional[torch.Tensor] = None,
-                    out: Optional[torch.Tensor] = None, causal: bool = False) -> torch.Tensor:
+                    out: Optional[torch.Tensor] = None, causal: bool = False, key_splits: int = 0) -> torch.Tensor:
     """q [B,Nq,H,hd], k/v [B,Nk,H,hd] bf16 views (last two dims dense; hd = 64, or 128 for the LLaMA prefill),
     q pre-scaled by scale*log2(e).  key_bias: optional fp32 [B,Nk] additive (natural-log units).
-    causal: query i sees keys <= i + (Nk - Nq).  Returns [B,Nq,H,hd] bf16."""
+    causal: query i sees keys <= i + (Nk - Nq).  key_splits > 1: the small-call key split.  Returns [B,Nq,H,hd] bf16."""
     hd = q.shape[3] if q.dim() == 4 else -1
     if hd not in (64, 128):
         raise RuntimeError("flash_attention: head size must be 64 or 128")
@@ -176,9 +177,14 @@ def flash_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, key_bias:
         _need(key_bias, torch.float32, "key_bias")
         if key_bias.shape != (B, Nk) or not key_bias.is_contiguous():
             raise RuntimeError("flash_attention: key_bias must be contiguous [B,Nk]")
+    part = lse = None
+    if key_splits > 1:
+        part = torch.empty((B * key_splits, Nq, H, hd), dtype=torch.bfloat16, device=q.device)
+        lse = torch.empty((B * key_splits, H, Nq), dtype=torch.float32, device=q.device)
     d = attn_desc(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, H, Nq, Nk,
                   q.stride(1), k.stride(1), v.stride(1), out.stride(1),
-                  q.stride(0), k.stride(0), v.stride(0), out.stride(0), _ptr(key_bias), head_dim=hd, causal=causal)
+                  q.stride(0), k.stride(0), v.stride(0), out.stride(0), _ptr(key_bias), head_dim=hd, causal=causal,
+                  key_splits=key_splits, o_part=_ptr(part), lse_part=_ptr(lse))
     run_attn(d)
     return out
 

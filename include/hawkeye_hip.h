@@ -111,6 +111,14 @@ typedef struct hk_attn_desc {
     int64_t bsq, bsk, bsv, bso;
     int32_t head_dim; /* 0 or 64 (ViT, Q-Former), 128 (LLaMA, row f1) */
     int32_t causal;   /* != 0: query q attends keys <= q + (Nk - Nq)  (modeling_llama.py:25-47) */
+    /* Key split for SMALL calls (B = 1 eval calls: 12..304 workgroups walking all keys one after the other): the keys
+     * are cut into key_splits slices of whole 64-key tiles, each (batch, head, query block, slice) is a workgroup that
+     * writes its normalised partial output and the rows' log2-sum-exp, and a second launch of the same call combines
+     * them (weights 2^(lse_s - max), slices in index order).  0 or 1 = off.  Head size 64, no key_bias, not causal.
+     * o_part: bf16 [B * key_splits * Nq * H * 64]; lse_part: fp32 [B * key_splits * H * Nq]. */
+    int32_t key_splits;
+    void* o_part;
+    float* lse_part;
 } hk_attn_desc;
 
 int hk_flash_attn_bf16(const hk_attn_desc* d, void* stream);

@@ -37,7 +37,7 @@ def test_struct_layout_matches_header():
     assert C.sizeof(L.HkRows) == 24
     assert C.sizeof(L.HkGemmDesc) == 5 * 8 + 16 + 24 + 8 + 24 + 24 + 24 + 3 * 8 + 8 + 8   # 4 int32 + float, padded to 8
     assert L.HkGemmDesc.split_k.offset == 5 * 8 + 16 + 24 + 8 + 24 + 24 + 24 + 3 * 8 and L.HkGemmDesc.split_stride.offset % 8 == 0
-    assert C.sizeof(L.HkAttnDesc) == 5 * 8 + 16 + 8 * 8 + 8   # + head_dim, causal
+    assert C.sizeof(L.HkAttnDesc) == 5 * 8 + 16 + 8 * 8 + 8 + 8 + 16   # + head_dim, causal; key_splits (+pad), o_part, lse_part
 
 
 def test_bad_descriptors_are_rejected_with_text():

@@ -234,6 +234,23 @@ def test_residual_add_parts_updates_the_stream_and_leaves_row_statistics(rows, D
     assert ops.residual_add_parts(again, parts, 1e-6, want_stats=False) is None and torch.equal(again, got)
 
 
+@pytest.mark.parametrize("B,H,Nq,Nk,S", [(1, 16, 2352, 2352, 2), (1, 12, 96, 2352, 8), (2, 3, 130, 1000, 3), (1, 2, 64, 300, 4),
+                                        (1, 1, 32, 64, 4)])
+def test_attention_key_split_matches_the_unsplit_launch(B, H, Nq, Nk, S):
+    """hk_attn_desc.key_splits: slices of the keys on separate workgroups + the combine launch = the same attention
+    (partial outputs are bf16: one extra rounding), incl. a ragged last slice and a split that degenerates to one slice."""
+    q = _rand((B, Nq, H, 64), 61, 1.3, dtype=torch.bfloat16)
+    k = _rand((B, Nk, H, 64), 62, dtype=torch.bfloat16)
+    v = _rand((B, Nk, H, 64), 63, dtype=torch.bfloat16)
+    k[:, Nk // 3] *= 6.0                                  # a key that dominates: the slices' maxima differ widely
+    ref = _attn_ref(q, k, v)
+    whole = ops.flash_attention(q, k, v)
+    split = ops.flash_attention(q, k, v, key_splits=S)
+    assert _rel(whole.float(), ref) < 2e-2 and _rel(split.float(), ref) < 2e-2
+    assert _rel(split.float(), whole.float()) < 1.5e-2
+    assert torch.equal(split, ops.flash_attention(q, k, v, key_splits=S))     # fixed combine order
+
+
 def test_gemm_rejects_bad_shapes():
     x = _rand((8, 48), 1, dtype=torch.bfloat16)
     w = _rand((16, 48), 2, dtype=torch.bfloat16)
