@@ -189,7 +189,7 @@ def main():
                       "vit.fc1_gelu": 2.0 * R_ * D_ * 4 * D_, "vit.fc2": 2.0 * R_ * D_ * 4 * D_,
                       "vit.patch_embed": 2.0 * R_ * cfg.patch_k * D_,
                       "qformer.cross_kv": 2.0 * R_ * D_ * 2 * cfg.qf_hidden * 6}
-            kname = {"vit.attn": "hk_attn_kernel<false, 1, 3, 1>", "vit.qkv": "hk_gemm_pp_kernel<3>",
+            kname = {"vit.attn": "hk_attn_kernel<false, 1, 3, 1, false>", "vit.qkv": "hk_gemm_pp_kernel<3>",
                      "vit.fc1_gelu": "hk_gemm_pp_kernel<3>", "vit.fc2": "hk_gemm_pp_kernel<4>", "vit.proj": "hk_gemm_pp_kernel<4>"}
             eng = model.sync_engine()
             table = model._table(T == 1, N_, dev)
