@@ -553,6 +553,14 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
         }
     };
 
+    // (Measured and not kept: starting eight classes of workgroups a fraction of a tile time apart (s_sleep), so that
+    // a CU's epilogue stores would meet the others' main loops instead of 255 other store bursts: every launch got slower
+    // by exactly the largest delay, fc1 850 -> 885 / 921 / 960 us at 1 / 2 / 4 sleep units -- the epilogue is not bound by
+    // the synchronised write burst.  What the bf16-out epilogue of a 256x256 tile costs, from diagnostic builds that drop
+    // parts of it (fc1 shape, one box, us per launch, 24.5 tiles per CU): complete 760 (no activation) / 960 (GELU); without
+    // the global stores 706 / 878; without the bias / GELU math 726 / 834; without both 660 / 750; without any epilogue
+    // 616 / 694 -- stores 7-9 %, GELU math 10 %, LDS transpose + pack + the idle matrix pipe around them the rest: no
+    // single part dominates, and none overlaps the main loop.)
     // ---- prologue: K-tile 0 of the stream complete, A-half0 of K-tile 1 in flight ----
     stage(0);
     stage(1);

@@ -147,16 +147,21 @@ def load() -> C.CDLL:
 
 
 def source_digest() -> str:
-    """sha1 over the kernel sources and the header the library is built from: profiles taken with another kernel
-    tree (profiles/traffic.json) are recognised as stale by it."""
+    """sha1 over the kernel sources and the header the library is built from, comments and white space removed:
+    profiles taken with another kernel tree (profiles/traffic.json) are recognised as stale by it, while a note added
+    to a comment does not orphan them."""
     import glob
     import hashlib
+    import re
     h = hashlib.sha1()
     files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")))
     files.append(os.path.join(os.path.dirname(_HERE), "include", "hawkeye_hip.h"))
     for f in files:
+        text = open(f, "r", errors="replace").read()
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)      # block comments
+        text = re.sub(r"//[^\n]*", " ", text)                   # line comments (no '//' occurs inside a string here)
         h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+        h.update(" ".join(text.split()).encode())
     return h.hexdigest()[:16]
 
 
