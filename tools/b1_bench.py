@@ -15,7 +15,10 @@ model = HawkEyeEncoder(cfg, out_dtype=torch.bfloat16)
 model.load_state_dict(W.make_state_dict(cfg, 1), strict=True)
 model = model.to(DEV).eval()
 model.device_pos_embed = True
-for B, T in ((1, 1), (1, 8), (1, 12), (1, 16), (4, 12), (4, 16)):
+SHAPES = ((1, 1), (1, 8), (1, 12), (1, 16), (4, 12), (4, 16))
+if len(sys.argv) > 1:      # e.g. 8x12,8x16
+    SHAPES = tuple(tuple(int(v) for v in a.split('x')) for a in sys.argv[1].split(','))
+for B, T in SHAPES:
     image = W.make_clip(B, T, cfg.img_size, 7).to(DEV)
     ids, mask = W.make_instruction_ids(B, 32, cfg.qf_vocab, 7)
     ids, mask = ids.to(DEV), mask.to(DEV)
