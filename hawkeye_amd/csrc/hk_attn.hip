@@ -364,7 +364,10 @@ __global__ __launch_bounds__(256, OCC) void hk_attn_kernel(const AttnParams p) {
         };
         auto exp_sum = [&]() __attribute__((always_inline)) {
             // (row sums over register pairs with v_pk_add_f32 -- 16 packed adds instead of 32 scalar ones -- measured 7 %
-            // SLOWER per launch, 1357 -> 1455 us same box: packed fp32 issues dearly beside MFMAs, like v_dot2c before it)
+            // SLOWER per launch, 1357 -> 1455 us same box: packed fp32 issues dearly beside MFMAs, like v_dot2c before it;
+            // row sums on the matrix pipe instead -- ones(32 x 16) . P^T as a 5th MFMA per 16-key step of the no-maximum
+            // pass, no v_add_f32 at all, 168 registers, no scratch -- measured 1420 -> 1470 us with two of the four steps
+            // summed that way and 1507 us with all four: the matrix pipe has no room either)
             rs = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
