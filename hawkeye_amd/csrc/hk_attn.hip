@@ -70,6 +70,12 @@ __device__ __forceinline__ float half_swap_sum(float x) {
     return a + b;
 }
 
+// Measured and not kept (round 2): 64 query rows per wave -- this tile body over two 32-row query blocks, so one K / V^T
+// fragment read and one LDS-DMA piece feed twice the MFMAs; 256 rows per workgroup, two workgroups per CU, 232 registers
+// and no scratch in the no-maximum form (with the running maximum and its redo path: 2.4 KB of scratch) -- 1355 -> 1396 us
+// per launch at B=32 N=3136 (13 blocks of 256 rows for 12.25), i.e. no gain per row: the loop is not waiting on LDS reads
+// or DMA issue.
+//
 // SPLIT: the key-split form (small calls) is an instantiation of its own -- its extra live scalars (slice base
 // pointers, slice length, lse pointer) cost the production instantiation SGPR spills and 20 bytes of scratch when
 // they shared one body.
