@@ -560,7 +560,9 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
     // parts of it (fc1 shape, one box, us per launch, 24.5 tiles per CU): complete 760 (no activation) / 960 (GELU); without
     // the global stores 706 / 878; without the bias / GELU math 726 / 834; without both 660 / 750; without any epilogue
     // 616 / 694 -- stores 7-9 %, GELU math 10 %, LDS transpose + pack + the idle matrix pipe around them the rest: no
-    // single part dominates, and none overlaps the main loop.)
+    // single part dominates, and none overlaps the main loop.  Without the LDS transpose -- a lane storing 2 x 16 B of one
+    // row straight from its accumulators, 16-byte pieces 32 bytes apart per instruction, a timing probe with the columns
+    // left unpermuted -- qkv 690 -> 762 us and fc1+GELU 852 -> 977 us: whole 128-byte row segments are worth the transpose.)
     // ---- prologue: K-tile 0 of the stream complete, A-half0 of K-tile 1 in flight ----
     stage(0);
     stage(1);
