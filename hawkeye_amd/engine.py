@@ -293,17 +293,29 @@ class HipEncoderEngine:
     def split_k_residual(self, M: int, N: int, K: int) -> int:
         """Split-K factor of a proj / fc2 update of the residual stream on a SMALL call (B = 1 eval calls: fc2 at
         M = 1568 is 104 workgroups walking 64 K-tiles one after the other, a latency chain).  Only while the slices
-        still fit one workgroup per CU with the deep (4-stage) pipeline and are at least 16 K-tiles long: measured on one
-        box, B = 1: T = 8 5.42 -> 5.07 ms; at T = 12 / 16 (152 / 200 tiles: the slices would need the 2-stage kernel at
-        two workgroups per CU, and the fp32 slices cost more than the shorter chain saves) 5.87 -> 6.01 / 6.05 -> 6.74 ms,
-        so those stay unsplit."""
+        make at most one workgroup per CU and are at least 16 K-tiles long.  With 128x128 tiles that covered T <= 8 only
+        (measured on one box, B = 1: T = 8 5.42 -> 5.07 ms; T = 12 / 16, 152 / 200 tiles, 5.87 -> 6.01 / 6.05 -> 6.74 ms:
+        two workgroups per CU on the 2-stage kernel, and the fp32 slices cost more than the shorter chain saves); with
+        256x128 tiles the slices of T = 6 ... 16 fit one round too (below)."""
         if os.environ.get("HK_SPLIT_K", "1") == "0" or self.residual_dtype != torch.bfloat16 or not self.fold_ln:
             return 1
         if -(-M // 256) * -(-N // 256) >= 128:       # the persistent kernel takes it
             return 1
-        t128 = -(-M // 128) * -(-N // 128)
         kt = K // 64
-        s = min(int(os.environ.get("HK_SPLIT_K_VIT", "4")), 256 // max(t128, 1), kt // 16)   # the switch: A/B aid
+        cap = int(os.environ.get("HK_SPLIT_K_VIT", "4"))   # the switch: A/B aid
+        # one round of 256x128 tiles when the slices make 160-256 of them (the dispatcher's rule for these launches):
+        # tools/small_gemm.py, fc2 + the consumer's sum against unsplit + row_stats_finalize: M = 2352 (T = 12) 3 slices
+        # 37.4 vs 50.3 us, M = 3136 (T = 16) 2 slices 45.0 vs 51.6, M = 1568 (T = 8) 4 slices 30.1 vs 36.8; proj (K = 1024:
+        # slices under 16 K-tiles) gains nothing and stays unsplit.  In whole calls (tools/b1_bench.py, same box, both rules
+        # of HK_GEMM_MID on / off): B = 1 T = 8 4.97 -> 4.45 ms, T = 10 5.20 -> 4.70, T = 12 5.72 -> 5.31, B = 2 T = 4 4.74 -> 4.20;
+        # the 2-slice case (M = 3136: B = 1 T = 16, B = 2 T = 8) measured +1 % in the call and is left unsplit
+        if os.environ.get("HK_GEMM_MID", "1") != "0":
+            tmid = -(-M // 256) * -(-N // 128)
+            s = min(cap, 256 // max(tmid, 1), kt // 16)
+            if s >= 3 and tmid * s >= 160:
+                return s
+        t128 = -(-M // 128) * -(-N // 128)
+        s = min(cap, 256 // max(t128, 1), kt // 16)
         return s if s >= 2 else 1
 
     def _build_plan(self, B: int, T: int, Lt: int) -> _Plan:

@@ -79,7 +79,7 @@ def test_gemm_epilogues_and_row_maps():
     assert _rel(out2, ref2) < 2e-5
 
 
-@pytest.mark.parametrize("M,N,K", [(66000, 1024, 256), (300, 768, 128)])
+@pytest.mark.parametrize("M,N,K", [(66000, 1024, 256), (300, 768, 128), (5000, 1024, 128)])   # the last: 160 tiles of 256x128
 def test_gemm_bf16_residual_in_place(M, N, K):
     """The bf16 residual stream: C = bf16(x @ w.T + b + float(C)), rounded once, C updated in place."""
     x = _rand((M, K), 81, dtype=torch.bfloat16)
@@ -130,7 +130,9 @@ def test_gemm_split_tail_rows_match_a_plain_launch(M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K,act", [(512, 768, 1024, "none"), (66000, 1024, 1024, "gelu"), (300, 272, 128, "gelu"),
-                                         (100352 // 4 + 7, 3072, 1024, "none")])
+                                         (100352 // 4 + 7, 3072, 1024, "none"),
+                                         # one round of 256x128 tiles (B = 1 calls): qkv at T = 12 (240 tiles), fc1 at T = 8 (224)
+                                         (2352, 3072, 1024, "none"), (1568 - 5, 4096, 1024, "gelu")])
 def test_gemm_with_folded_layernorm(M, N, K, act):
     """hk_row_stats + row_stats/col_c epilogue == LayerNorm -> Linear (-> GELU) in fp32 (vit.py:125-127), on a residual
     stream with a per-row offset and outlier channels (the mean term must cancel, not merely be small)."""
@@ -189,7 +191,9 @@ def test_gemm_row_part_feeds_the_next_layernorm(M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K,S", [(96, 768, 3072, 6), (32, 768, 3072, 8), (200, 768, 3072, 4), (96, 768, 768, 3),
-                                     (2352, 1024, 4096, 2), (130, 144, 320, 5)])
+                                     (2352, 1024, 4096, 2), (130, 144, 320, 5),
+                                     # slices that make one round of 256x128 tiles: fc2 at T = 12 (240) and T = 8 (224)
+                                     (2352, 1024, 4096, 3), (1568 - 3, 1024, 4096, 4)])
 def test_gemm_split_k_partials_and_layernorm_of_their_sum(M, N, K, S):
     """hk_gemm_desc.split_k: slice z multiplies its own K range; slice 0 carries bias + residual; the slices sum to the
     unsplit GEMM (fp32 reassociation only), and hk_layernorm_parts normalises the sum without a reduction pass."""

@@ -24,3 +24,12 @@ for name, N, K in (("qkv", 3072, 1024), ("proj", 1024, 1024), ("fc1", 4096, 1024
                           a_rows=(K, 128, 0) if bc else (K, 0, 0), c_rows=(N, 0, 0))
         us = timeit(lambda: ops.run_gemm(d), iters=50, warm=5)
         print(f"[{tag}] M={M} {name:5s} N={N} K={K} A-broadcast={int(bc)}: {us:7.1f} us {2.0 * M * N * K / us / 1e6:7.1f} TF", flush=True)
+    if name in ("proj", "fc2") and os.environ.get("SMALL_GEMM_SPLITS"):
+        res = torch.randn(M, N, device=DEV)
+        for S in (int(v) for v in os.environ["SMALL_GEMM_SPLITS"].split(",")):
+            xr = torch.randn(M, N, device=DEV).to(torch.bfloat16)
+            def both():
+                parts = ops.linear_split_k(x, w, b, None, S)
+                ops.residual_add_parts(xr, parts, 1e-6)
+            us = timeit(both, iters=50, warm=5)
+            print(f"[{tag}] M={M} {name:5s} N={N} K={K} split_k={S} + residual_add_parts: {us:7.1f} us", flush=True)
