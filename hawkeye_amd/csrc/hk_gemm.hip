@@ -960,7 +960,14 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
     // multi-stage kernel everywhere (A/B aid).
     const long tiles256 = (long)((d->M + 255) / 256) * ((d->N + 255) / 256);
     static const int variant = getenv("HK_GEMM_VARIANT") ? atoi(getenv("HK_GEMM_VARIANT")) : 1;
+    // HK_GEMM_MID=0 turns the 256x128-tile rule (below) off (A/B aid)
+    static const int mid = getenv("HK_GEMM_MID") ? atoi(getenv("HK_GEMM_MID")) : 1;
+    auto mid_window = [&](int M_) {
+        const long tiles_mid = (long)((M_ + 255) / 256) * ((d->N + 127) / 128);
+        return mid != 0 && variant != 0 && tiles_mid <= 256 && tiles_mid >= 160;
+    };
     auto small = [&](const GemmParams& q) {
+        if (mid_window(q.M)) return launch<256, 128, 4, 2, 2>(q, s);   // also the tail rows of a split persistent launch
         const long t128 = (long)((q.M + 127) / 128) * ((q.N + 127) / 128);
         if (q.row_part && t128 < 384) return launch<128, 128, 2, 2, 4>(q, s);  // 64 columns per wave: the row_part granule
         if (t128 >= 384) return launch<128, 128, 2, 2, 2>(q, s);  // >= 1.5 workgroups per CU: 2 stages, 2 workgroups per CU
@@ -993,9 +1000,8 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
         // one round of 256x128 tiles (160-256 workgroups) first, as for the unsplit launches below: fc2 at M = 2352 in 3
         // slices 50.4 -> 37.4 us with the consumer's sum (unsplit 45.6 + 4.7), M = 3136 in 2 slices 60.1 -> 45.0 (46.9 + 4.7),
         // M = 1568 in 4 slices 40.3 -> 30.1 (2 slices of 128x128 tiles: 33.0); HK_GEMM_MID=0 turns it off
-        static const int mid_sk = getenv("HK_GEMM_MID") ? atoi(getenv("HK_GEMM_MID")) : 1;
         const long tmid = (long)((d->M + 255) / 256) * ((d->N + 127) / 128) * p.ksplit;
-        if (mid_sk != 0 && tmid >= 160 && tmid <= 256) return launch<256, 128, 4, 2, 2>(p, s);
+        if (mid != 0 && tmid >= 160 && tmid <= 256) return launch<256, 128, 4, 2, 2>(p, s);
         if (t128 >= 384) return launch<128, 128, 2, 2, 2>(p, s);
         if (t128 >= 128) return launch<128, 128, 2, 2, 4>(p, s);
         return launch<128, 64, 2, 2, 4>(p, s);
@@ -1005,10 +1011,7 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
     // 128x128 ones -- tools/small_gemm.py, us per launch: M = 2352 qkv (240 tiles) 29.5 -> 25.2; M = 1568 qkv (168) 33.7 ->
     // 23.6, fc1 (224) 28.6 -> 23.9; it loses below (M = 784 qkv, 96 tiles: 18.6 -> 21.8; proj / fc2, 56-80 tiles: 17.7 -> 22.6,
     // 45 -> 60) and above one round (M = 2352 fc1, 320 tiles: 29 -> 42).  3 stages or 128x256 measured the same within 2 %.
-    // HK_GEMM_MID=0 turns the rule off (A/B aid).
-    static const int mid = getenv("HK_GEMM_MID") ? atoi(getenv("HK_GEMM_MID")) : 1;
-    const long tiles_mid = (long)((d->M + 255) / 256) * ((d->N + 127) / 128);
-    if (mid != 0 && variant != 0 && d->split_k <= 1 && tiles_mid <= 256 && tiles_mid >= 160) return launch<256, 128, 4, 2, 2>(p, s);
+    if (mid_window(d->M)) return small(p);
     if (variant != 0 && tiles256 >= pp_min && d->N % 256 == 0 && off32) {
         // Tail balance: the persistent kernel gives each of the 256 CUs floor or ceil(tiles / 256) tiles, so a
         // last round that is less than half full (e.g. 1568 tiles = 6.125 rounds) idles most of the chip for a
