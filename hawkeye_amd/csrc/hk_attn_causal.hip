@@ -252,15 +252,11 @@ __global__ __launch_bounds__(256, 1) void hk_attn_causal_kernel(const CausalPara
 template <int HD, bool BIAS>
 int launch_causal(const CausalParams& p, hipStream_t s) {
     constexpr int LDS = 2 * 2 * KT * HD * 2 + (BIAS ? 2 * KT * 4 : 0);
-    static bool attr_set = false;  // idempotent
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hk_attn_causal_kernel<HD, BIAS>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) {
-            hk_set_error("hk_flash_attn_bf16: hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e));
-            return HK_ELAUNCH;
-        }
-        attr_set = true;
+    static std::atomic<unsigned long long> attr_done{0};   // per device
+    const hipError_t e = hk_lds_attr_once(attr_done, reinterpret_cast<const void*>(&hk_attn_causal_kernel<HD, BIAS>), LDS);
+    if (e != hipSuccess) {
+        hk_set_error("hk_flash_attn_bf16: hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e));
+        return HK_ELAUNCH;
     }
     hipLaunchKernelGGL((hk_attn_causal_kernel<HD, BIAS>), dim3((unsigned)((long)p.nqb * p.H * p.B)), dim3(256), LDS, s, p);
     HK_CHECK_LAUNCH("hk_flash_attn_bf16");

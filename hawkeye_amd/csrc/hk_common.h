@@ -4,6 +4,21 @@
 #include <stdint.h>
 #include <stdio.h>
 #include "../../include/hawkeye_hip.h"
+#include <atomic>
+
+// Once per (kernel instantiation, device): hipFuncSetAttribute acts on the CURRENT device's copy of the function, and one
+// process may drive two devices (the two-device placement of set_device_ids).  `done` is a per-instantiation bit mask of
+// the devices already set up; racing first calls set the same value.  Returns hipSuccess or the failing call's error.
+static inline hipError_t hk_lds_attr_once(std::atomic<unsigned long long>& done, const void* func, int lds_bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if ((done.load(std::memory_order_acquire) >> dev) & 1ull) return hipSuccess;
+    e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e == hipSuccess) done.fetch_or(1ull << dev, std::memory_order_release);
+    return e;
+}
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;

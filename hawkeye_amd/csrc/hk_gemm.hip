@@ -817,15 +817,11 @@ __global__ __launch_bounds__(WM* WN * 64) void hk_gemm_kernel(const GemmParams p
 template <int BM, int BN, int WM, int WN, int STAGES>
 int launch(const GemmParams& p, hipStream_t stream) {
     constexpr int LDS = STAGES * (BM + BN) * 64 * 2;
-    static bool attr_set = false;  // idempotent; racing first calls set the same value
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hk_gemm_kernel<BM, BN, WM, WN, STAGES>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) {
-            hk_set_error("hk_gemm_bf16: hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e));
-            return HK_ELAUNCH;
-        }
-        attr_set = true;
+    static std::atomic<unsigned long long> attr_done{0};   // per device
+    const hipError_t e = hk_lds_attr_once(attr_done, reinterpret_cast<const void*>(&hk_gemm_kernel<BM, BN, WM, WN, STAGES>), LDS);
+    if (e != hipSuccess) {
+        hk_set_error("hk_gemm_bf16: hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e));
+        return HK_ELAUNCH;
     }
     GemmParams q = p;
     q.nbm = (p.M + BM - 1) / BM;
@@ -839,10 +835,17 @@ int launch(const GemmParams& p, hipStream_t stream) {
 template <int EPI>
 int launch_pp(const GemmParams& p, hipStream_t stream) {
     constexpr int LDS = 2 * 4 * 128 * 64 * 2 + 8 * 4096;  // operand buffers + epilogue staging = 160 KB
-    static int ncu = 0;  // idempotent; racing first calls compute the same values
+    static std::atomic<unsigned long long> attr_done{0};   // per device
+    {
+        const hipError_t e = hk_lds_attr_once(attr_done, reinterpret_cast<const void*>(&hk_gemm_pp_kernel<EPI>), LDS);
+        if (e != hipSuccess) {
+            hk_set_error("hk_gemm_bf16: hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e));
+            return HK_ELAUNCH;
+        }
+    }
+    static int ncu = 0;  // CUs per device (one device model per process); racing first calls compute the same value
     if (ncu == 0) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hk_gemm_pp_kernel<EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipSuccess;
         int dev = 0, n = 0;
         if (e == hipSuccess) e = hipGetDevice(&dev);
         if (e == hipSuccess) e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
