@@ -282,11 +282,13 @@ class HipEncoderEngine:
             return 1
         tiles = -(-rows // 128) * -(-N // 64)
         kt = K // 64
-        if tiles > 128 or kt < 24:
+        # HK_SPLIT_K_SHORT=0 (A/B aid): only the long contractions (K >= 1536), as before the 768 -> 768 layers joined
+        short = os.environ.get("HK_SPLIT_K_SHORT", "1") != "0"
+        if tiles > 128 or kt < (12 if short else 24):
             return 1
         best = 1
         for s in range(2, 9):
-            if kt % s == 0 and kt // s >= 6 and tiles * s <= 288:
+            if kt % s == 0 and kt // s >= (4 if kt < 24 else 6) and tiles * s <= 288:
                 best = s
         return best
 
@@ -371,6 +373,11 @@ class HipEncoderEngine:
                 sk_t = self.split_k_for(B * Lt, d, inter) if Lt > 0 else 1
                 parts_q = plan.buf("parts_q", (sk_q, B * nq, d), f32, dev) if sk_q > 1 else None
                 parts_t = plan.buf("parts_t", (sk_t, B * Lt, d), f32, dev) if sk_t > 1 else None
+                # the attention output layers (768 -> 768, 12 K-tiles) on a handful of workgroups: same treatment
+                sk_a = self.split_k_for(B * S, d, d)
+                sk_c = self.split_k_for(B * nq, d, d)
+                parts_a = plan.buf("parts_a", (sk_a, B * S, d), f32, dev) if sk_a > 1 else None
+                parts_c = plan.buf("parts_c", (sk_c, B * nq, d), f32, dev) if sk_c > 1 else None
 
         P = lambda t: t.data_ptr()  # noqa: E731
         plain = lambda ld: (ld, 0, 0)  # noqa: E731
@@ -476,18 +483,32 @@ class HipEncoderEngine:
                            a_rows=plain(d), c_rows=plain(3 * d), scale_cols=d, scale=qscale)
                 self._attn(plan, P(qqkv), P(qqkv) + d * eb, P(qqkv) + 2 * d * eb, P(ctx), B, Hq, S, S,
                            3 * d, 3 * d, 3 * d, d, S * 3 * d, S * 3 * d, S * 3 * d, S * d, key_bias=P(kbias))
-                self._gemm(plan, P(ctx), w[o + "ao.w"], P(tf), B * S, d, d, bias=P(w[o + "ao.b"]), residual=P(hf),
-                           a_rows=plain(d), c_rows=plain(d), r_rows=plain(d), out_f32=True)
-                self._ln(plan, P(tf), True, w[o + "ao.g"], w[o + "ao.bt"], P(ab), P(af), B * S, d, cfg.qf_ln_eps)
+                if sk_a > 1:
+                    self._gemm(plan, P(ctx), w[o + "ao.w"], P(parts_a), B * S, d, d, bias=P(w[o + "ao.b"]), residual=P(hf),
+                               a_rows=plain(d), c_rows=plain(d), r_rows=plain(d), out_f32=True, split_k=sk_a,
+                               split_stride=B * S * d)
+                    self._ln_parts(plan, P(parts_a), sk_a, B * S * d, w[o + "ao.g"], w[o + "ao.bt"], P(ab), P(af), B * S, d,
+                                   cfg.qf_ln_eps)
+                else:
+                    self._gemm(plan, P(ctx), w[o + "ao.w"], P(tf), B * S, d, d, bias=P(w[o + "ao.b"]), residual=P(hf),
+                               a_rows=plain(d), c_rows=plain(d), r_rows=plain(d), out_f32=True)
+                    self._ln(plan, P(tf), True, w[o + "ao.g"], w[o + "ao.bt"], P(ab), P(af), B * S, d, cfg.qf_ln_eps)
                 fork = len(plan.steps)
                 if i % cfg.cross_attention_freq == 0:
                     self._gemm(plan, P(ab), w[o + "cq.w"], P(cq), B * nq, d, d, bias=P(w[o + "cq.b"]),
                                a_rows=qrows, c_rows=plain(d), scale_cols=d, scale=qscale)
                     self._attn(plan, P(cq), P(kvc) + ci * 2 * d * eb, P(kvc) + (ci * 2 + 1) * d * eb, P(cctx), B, Hq, nq, N,
                                d, KVW, KVW, d, nq * d, N * KVW, N * KVW, nq * d)
-                    self._gemm(plan, P(cctx), w[o + "co.w"], P(tf), B * nq, d, d, bias=P(w[o + "co.b"]), residual=P(af),
-                               a_rows=plain(d), c_rows=plain(d), r_rows=qrows, out_f32=True)
-                    self._ln(plan, P(tf), True, w[o + "co.g"], w[o + "co.bt"], P(cb), P(cf), B * nq, d, cfg.qf_ln_eps)
+                    if sk_c > 1:
+                        self._gemm(plan, P(cctx), w[o + "co.w"], P(parts_c), B * nq, d, d, bias=P(w[o + "co.b"]), residual=P(af),
+                                   a_rows=plain(d), c_rows=plain(d), r_rows=qrows, out_f32=True, split_k=sk_c,
+                                   split_stride=B * nq * d)
+                        self._ln_parts(plan, P(parts_c), sk_c, B * nq * d, w[o + "co.g"], w[o + "co.bt"], P(cb), P(cf), B * nq, d,
+                                       cfg.qf_ln_eps)
+                    else:
+                        self._gemm(plan, P(cctx), w[o + "co.w"], P(tf), B * nq, d, d, bias=P(w[o + "co.b"]), residual=P(af),
+                                   a_rows=plain(d), c_rows=plain(d), r_rows=qrows, out_f32=True)
+                        self._ln(plan, P(tf), True, w[o + "co.g"], w[o + "co.bt"], P(cb), P(cf), B * nq, d, cfg.qf_ln_eps)
                     qin_b, qin_f, qin_rows = P(cb), P(cf), plain(d)
                     ci += 1
                 else:
