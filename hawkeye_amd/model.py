@@ -31,9 +31,19 @@ from .engine import HipEncoderEngine
 from .train import QFormerTrainEngine, trainable_names
 
 
+# Bumped whenever a module or parameter is (re)assigned on one of this file's container modules; HawkEyeEncoder keys its
+# cached list of parameter slots on it (see HawkEyeEncoder._weights_key).
+_STRUCTURE_VERSION = [0]
+
+
 class _NoForward(nn.Module):
     def forward(self, *a, **k):  # pragma: no cover - guard
         raise RuntimeError(f"{type(self).__name__} is a parameter container; run HawkEyeEncoder.encode_img")
+
+    def __setattr__(self, name, value):
+        if isinstance(value, (nn.Module, nn.Parameter)):
+            _STRUCTURE_VERSION[0] += 1
+        super().__setattr__(name, value)
 
 
 class _Attention(_NoForward):          # vit.py:57-79
@@ -280,7 +290,18 @@ class HawkEyeEncoder(nn.Module):
     # ---- reference module protocol -------------------------------------------------
     @property
     def device(self):
-        return list(self.parameters())[0].device
+        # blip2.py:43-44: the device of the module's FIRST parameter (query_tokens), without listing all 700 of them
+        return next(self.parameters()).device
+
+    def __setattr__(self, name, value):
+        if isinstance(value, (nn.Module, nn.Parameter)):
+            _STRUCTURE_VERSION[0] += 1
+        super().__setattr__(name, value)
+
+    def invalidate_parameter_cache(self):
+        """Forget the cached parameter slots (see _weights_key).  Needed only after replacing an ITEM of a ModuleList
+        (`blocks[i] = ...`, `layer[i] = ...`); every other replacement or in-place change is seen without it."""
+        _STRUCTURE_VERSION[0] += 1
 
     def set_device_ids(self, device_ids):           # hawkeye_it.py:197-211
         """One id: everything on that GPU.  Two ids: the reference's optional split -- vision_encoder +
@@ -341,9 +362,27 @@ class HawkEyeEncoder(nn.Module):
 
     # ---- engine plumbing -----------------------------------------------------------
     def _weights_key(self, part: str):
-        vit = part == "vit"
-        return tuple((p.data_ptr(), p._version) for n, p in self.named_parameters()
-                     if n.startswith(("vision_encoder.", "vision_layernorm.")) == vit)
+        """(data_ptr, version) of every parameter of one half: changes when a parameter is replaced, moved or modified
+        in place.  Walking named_parameters() over ~230 modules costs 0.5-0.8 ms per half -- host time that is NOT
+        hidden behind the device when the caller syncs on every result, as the eval scripts do -- so the walk is done
+        once per module structure and what is re-read per call are the (module, name) slots it found: a parameter
+        replaced in its slot, `.data` swapped by .to() / .float(), an optimizer step or a load_state_dict all show up;
+        modules or parameters assigned on this file's containers bump the structure version."""
+        cache = self.__dict__.get("_slot_cache")
+        if cache is None or cache[0] != _STRUCTURE_VERSION[0]:
+            slots = {"vit": [], "qformer": []}
+            for mname, mod in self.named_modules():
+                half = "vit" if (mname + ".").startswith(("vision_encoder.", "vision_layernorm.")) else "qformer"
+                for pname in mod._parameters:
+                    if mod._parameters[pname] is not None:
+                        slots[half].append((mod._parameters, pname))
+            cache = (_STRUCTURE_VERSION[0], slots)
+            self.__dict__["_slot_cache"] = cache
+        key = []
+        for params, pname in cache[1][part]:
+            p = params[pname]
+            key.append((p.data_ptr(), p._version))
+        return tuple(key)
 
     def sync_engine(self, force: bool = False, parts=("vit", "qformer")) -> HipEncoderEngine:
         """(Re)pack device weights when a parameter was replaced or modified in place.  The two halves are tracked
