@@ -368,6 +368,15 @@ class HawkEyeEncoder(nn.Module):
         once per module structure and what is re-read per call are the (module, name) slots it found: a parameter
         replaced in its slot, `.data` swapped by .to() / .float(), an optimizer step or a load_state_dict all show up;
         modules or parameters assigned on this file's containers bump the structure version."""
+        key = []
+        for params, pname in self._slots(part):
+            p = params[pname]
+            key.append((p.data_ptr(), p._version))
+        return tuple(key)
+
+    def _slots(self, part: str):
+        """[(module._parameters, name)] of one half ("vit": vision_encoder + vision_layernorm; "qformer": the rest), in
+        named_parameters() order; rebuilt when the structure version moved."""
         cache = self.__dict__.get("_slot_cache")
         if cache is None or cache[0] != _STRUCTURE_VERSION[0]:
             slots = {"vit": [], "qformer": []}
@@ -378,11 +387,10 @@ class HawkEyeEncoder(nn.Module):
                         slots[half].append((mod._parameters, pname))
             cache = (_STRUCTURE_VERSION[0], slots)
             self.__dict__["_slot_cache"] = cache
-        key = []
-        for params, pname in cache[1][part]:
-            p = params[pname]
-            key.append((p.data_ptr(), p._version))
-        return tuple(key)
+        return cache[1][part]
+
+    def _any_requires_grad(self, part: str) -> bool:
+        return any(params[pname].requires_grad for params, pname in self._slots(part))
 
     def sync_engine(self, force: bool = False, parts=("vit", "qformer")) -> HipEncoderEngine:
         """(Re)pack device weights when a parameter was replaced or modified in place.  The two halves are tracked
@@ -554,8 +562,7 @@ class HawkEyeEncoder(nn.Module):
     def _encode(self, image, instruction, norm):
         device = image.device
         dropout = self.qformer.training
-        need_grad = torch.is_grad_enabled() and any(
-            p.requires_grad for n, p in self.named_parameters() if not n.startswith(("vision_encoder.", "vision_layernorm.")))
+        need_grad = torch.is_grad_enabled() and self._any_requires_grad("qformer")
         train_path = dropout or need_grad
         if self.low_resource:
             raise NotImplementedError("low_resource (ViT in fp32 on the CPU, hawkeye_it.py:213-223) is not offered: the "
