@@ -967,7 +967,8 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
     static const int mid = getenv("HK_GEMM_MID") ? atoi(getenv("HK_GEMM_MID")) : 1;
     auto mid_window = [&](int M_) {
         const long tiles_mid = (long)((M_ + 255) / 256) * ((d->N + 127) / 128);
-        return mid != 0 && variant != 0 && tiles_mid <= 256 && tiles_mid >= 160;
+        static const int mid_lo = getenv("HK_GEMM_MID_LO") ? atoi(getenv("HK_GEMM_MID_LO")) : 144;   // see the rule below
+        return mid != 0 && variant != 0 && tiles_mid <= 256 && tiles_mid >= mid_lo;
     };
     auto small = [&](const GemmParams& q) {
         if (mid_window(q.M)) return launch<256, 128, 4, 2, 2>(q, s);   // also the tail rows of a split persistent launch
@@ -1009,11 +1010,14 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
         if (t128 >= 128) return launch<128, 128, 2, 2, 4>(p, s);
         return launch<128, 64, 2, 2, 4>(p, s);
     }
-    // Between the two: when 256x128 tiles make ONE round that fills 5/8 of the chip or more (160-256 tiles; B = 1 calls at
-    // T = 8-12), the multi-stage kernel at that tile beats both the half-empty round of 256x256 tiles and two rounds of
-    // 128x128 ones -- tools/small_gemm.py, us per launch: M = 2352 qkv (240 tiles) 29.5 -> 25.2; M = 1568 qkv (168) 33.7 ->
-    // 23.6, fc1 (224) 28.6 -> 23.9; it loses below (M = 784 qkv, 96 tiles: 18.6 -> 21.8; proj / fc2, 56-80 tiles: 17.7 -> 22.6,
-    // 45 -> 60) and above one round (M = 2352 fc1, 320 tiles: 29 -> 42).  3 stages or 128x256 measured the same within 2 %.
+    // Between the two: when 256x128 tiles make ONE round that fills 9/16 of the chip or more (144-256 tiles; B = 1 calls at
+    // T = 7-12, B = 2-5 at T = 8-16 for the N = 1024 layers), the multi-stage kernel at that tile beats both the half-empty
+    // round of 256x256 tiles and two rounds of 128x128 ones -- tools/small_gemm.py, us per launch: M = 2352 qkv (240 tiles)
+    // 29.5 -> 25.2; M = 1568 qkv (168) 33.7 -> 23.6, fc1 (224) 28.6 -> 23.9; it loses below (M = 784 qkv, 96 tiles: 18.6 -> 21.8;
+    // proj / fc2, 56-80 tiles: 17.7 -> 22.6, 45 -> 60; whole calls with the bound at 128: B = 1 T = 4 / 5 +5 %) and above one
+    // round (M = 2352 fc1, 320 tiles: 29 -> 42).  3 stages or 128x256 measured the same within 2 %.  Whole calls, rule off /
+    // on: B = 2 T = 16 10.58 -> 9.48 ms, B = 4 T = 8 9.43 -> 8.35, B = 3 T = 12 10.05 -> 9.01; lower bound 160 -> 144: B = 2 T = 12
+    // 8.14 -> 7.55, B = 1 T = 7 4.53 -> 4.30.
     if (mid_window(d->M)) return small(p);
     if (variant != 0 && tiles256 >= pp_min && d->N % 256 == 0 && off32) {
         // Tail balance: the persistent kernel gives each of the 256 CUs floor or ceil(tiles / 256) tiles, so a
