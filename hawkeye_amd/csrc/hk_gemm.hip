@@ -1017,7 +1017,8 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
     // proj / fc2, 56-80 tiles: 17.7 -> 22.6, 45 -> 60; whole calls with the bound at 128: B = 1 T = 4 / 5 +5 %) and above one
     // round (M = 2352 fc1, 320 tiles: 29 -> 42).  3 stages or 128x256 measured the same within 2 %.  Whole calls, rule off /
     // on: B = 2 T = 16 10.58 -> 9.48 ms, B = 4 T = 8 9.43 -> 8.35, B = 3 T = 12 10.05 -> 9.01; lower bound 160 -> 144: B = 2 T = 12
-    // 8.14 -> 7.55, B = 1 T = 7 4.53 -> 4.30.
+    // 8.14 -> 7.55, B = 1 T = 7 4.53 -> 4.30.  Two or three rounds of these tiles for the N = 1024 layers (257-768 tiles, in place
+    // of a persistent round plus its tail) lose: B = 4 T = 12 11.47 -> 12.2 ms, B = 6 T = 12 14.86 -> 15.9, B = 8 T = 12 20.3 -> 20.95.
     if (mid_window(d->M)) return small(p);
     if (variant != 0 && tiles256 >= pp_min && d->N % 256 == 0 && off32) {
         // Tail balance: the persistent kernel gives each of the 256 CUs floor or ceil(tiles / 256) tiles, so a
