@@ -370,8 +370,8 @@ class HawkEyeEncoder(nn.Module):
         modules or parameters assigned on this file's containers bump the structure version."""
         key = []
         for params, pname in self._slots(part):
-            p = params[pname]
-            key.append((p.data_ptr(), p._version))
+            p = params.get(pname)
+            key.append((p.data_ptr(), p._version) if p is not None else (0, 0))   # a slot emptied since the walk
         return tuple(key)
 
     def _slots(self, part: str):
@@ -390,7 +390,7 @@ class HawkEyeEncoder(nn.Module):
         return cache[1][part]
 
     def _any_requires_grad(self, part: str) -> bool:
-        return any(params[pname].requires_grad for params, pname in self._slots(part))
+        return any(p is not None and p.requires_grad for p in (params.get(pname) for params, pname in self._slots(part)))
 
     def sync_engine(self, force: bool = False, parts=("vit", "qformer")) -> HipEncoderEngine:
         """(Re)pack device weights when a parameter was replaced or modified in place.  The two halves are tracked
