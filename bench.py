@@ -144,6 +144,7 @@ def main():
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
     wall = hdist.max_over_ranks(wall, dev)
+    seen = hdist.ranks_seen(dev)        # every rank reports itself over the job's own (RCCL) group
 
     if rank == 0:
         clips = world * B * args.steps
@@ -179,6 +180,9 @@ def main():
                        "vit_blocks": cfg.run_depth, "parallelism": f"clip-sharded x{world}",
                        "output_all_gather": bool(gather)},
             "roofline": dict(step_roof, bound="mfma", step=step_roof),
+            # one entry per rank, gathered over RCCL: N entries with N distinct (local_rank, device_index) = the
+            # collective spanned N ranks on N GPUs
+            "ranks_seen": seen,
         }
         if not args.no_insitu:
             # Dominant kernel, in situ: one HIP event pair around every launch of 3 more calls (same stream and order as

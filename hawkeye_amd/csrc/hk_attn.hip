@@ -1001,6 +1001,8 @@ extern "C" int hk_flash_attn_bf16(const hk_attn_desc* d, void* stream) {
                "hk_flash_attn_bf16: strides must keep 16-byte (Q,K,V) / 8-byte (O) alignment");
     HK_REQUIRE(d->head_dim == 0 || d->head_dim == 64 || d->head_dim == 128,
                "hk_flash_attn_bf16: head_dim %d not supported (64 or 128)", d->head_dim);
+    HK_REQUIRE(d->key_splits <= 1 || (d->causal == 0 && d->head_dim != 128),
+               "hk_flash_attn_bf16: key_splits needs head size 64 and a non-causal problem");
     if (d->causal != 0 || d->head_dim == 128) return hk_attn_causal_dispatch(d, stream);
     AttnParams p;
     p.Q = reinterpret_cast<const __bf16*>(d->Q);

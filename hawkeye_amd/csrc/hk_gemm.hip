@@ -20,6 +20,15 @@
 #include <stdlib.h>
 #include "hk_common.h"
 
+// Diagnostic switches (timing-only kernels, phase stamps) exist only in the -DHK_DIAG build (make diag)
+#ifdef HK_DIAG
+#define HK_DBG(p) ((p).dbg)
+#define HK_TRACE(p) ((p).trace)
+#else
+#define HK_DBG(p) 0
+#define HK_TRACE(p) ((unsigned long long*)nullptr)
+#endif
+
 namespace {
 
 struct RowMap {
@@ -232,7 +241,7 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
     const int c0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
     const int cnt = q8 + (xcd < r8 ? 1 : 0);
     const int ntile = jb < cnt ? (cnt - jb + nbx - 1) / nbx : 0;
-    const int KT = (p.dbg & 2) ? 1 : p.K / BK;  // dbg 2: timing-only build, one K-tile per tile
+    const int KT = (HK_DBG(p) & 2) ? 1 : p.K / BK;  // dbg 2: timing-only build, one K-tile per tile
     if (ntile == 0) return;                      // uniform per workgroup
 
     // ---- loader: one LDS-DMA wave-instruction = 8 rows x 128 B; a half-tile = 2 per thread.
@@ -339,7 +348,7 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
     // same way.  Bias, column scale and GELU are applied on the accumulator layout, before LDS.
     char* stg = smem + 2 * BUF * 2 + wave * 4096;
     auto epilogue = [&](int m0, int n0) {
-        if (p.dbg & 1) {  // dbg 1: timing-only build, no epilogue (accumulators kept live)
+        if (HK_DBG(p) & 1) {  // dbg 1: timing-only build, no epilogue (accumulators kept live)
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -576,7 +585,7 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
     HK_BAR();
     if (wm == 1) HK_BAR();  // stagger group 1 by one barrier
 
-    unsigned long long* trc = p.trace ? p.trace + (size_t)blockIdx.x * 64 : nullptr;
+    unsigned long long* trc = HK_TRACE(p) ? HK_TRACE(p) + (size_t)blockIdx.x * 64 : nullptr;
     if (trc && tid == 0) {
         trc[0] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
         trc[1] = __builtin_amdgcn_s_memrealtime();
@@ -862,8 +871,9 @@ int launch_pp(const GemmParams& p, hipStream_t stream) {
     // HK_GEMM_VARIANT=2: one tile per workgroup (grid = tiles) instead of the persistent walk
     static const int variant = getenv("HK_GEMM_VARIANT") ? atoi(getenv("HK_GEMM_VARIANT")) : 1;
     const int grid = (variant == 2 || ntiles < ncu) ? ntiles : ncu;
-    // HK_GEMM_TRACE=<file>: debug only -- per-workgroup timestamps of the LAST launch are dumped (this path
-    // allocates and synchronises; never set it in production)
+#ifdef HK_DIAG
+    // diagnostic build only (make diag -> libhawkeye_hip_diag.so): HK_GEMM_TRACE=<file> dumps per-workgroup timestamps of
+    // the LAST launch.  This path allocates and synchronises, so it is compiled out of the product library.
     static const char* trace_path = getenv("HK_GEMM_TRACE");
     static unsigned long long* trace_buf = nullptr;
     if (trace_path) {
@@ -871,8 +881,10 @@ int launch_pp(const GemmParams& p, hipStream_t stream) {
         if (trace_buf) (void)hipMemsetAsync(trace_buf, 0, (size_t)16384 * 64 * 8, stream);
         q.trace = grid <= 16384 ? trace_buf : nullptr;
     }
+#endif
     hipLaunchKernelGGL(hk_gemm_pp_kernel<EPI>, dim3(grid), dim3(512), LDS, stream, q);
     HK_CHECK_LAUNCH("hk_gemm_bf16");
+#ifdef HK_DIAG
     if (trace_path && q.trace) {
         (void)hipStreamSynchronize(stream);
         unsigned long long* h = (unsigned long long*)malloc((size_t)grid * 64 * 8);
@@ -884,6 +896,7 @@ int launch_pp(const GemmParams& p, hipStream_t stream) {
         }
         free(h);
     }
+#endif
     return HK_OK;
 }
 
@@ -924,6 +937,16 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
                                    (d->residual == nullptr || d->residual != d->C)),
                "hk_gemm_bf16: split_k needs fp32 output, no activation / folded LayerNorm / row_part, split_k <= K / 64, "
                "and a residual that is not the output buffer");
+    if (d->split_k > 1) {
+        // slice z lives at C + z * split_stride: a stride shorter than one slice's extent makes slices overwrite each other
+        const int64_t c_last = d->c_rows.rows_per_batch == 0
+                                   ? (int64_t)(d->M - 1) * d->c_rows.ld
+                                   : (int64_t)((d->M - 1) / d->c_rows.rows_per_batch) * d->c_rows.batch_stride +
+                                         (int64_t)((d->M - 1) % d->c_rows.rows_per_batch) * d->c_rows.ld;
+        HK_REQUIRE(d->split_stride >= c_last + d->N,
+                   "hk_gemm_bf16: split_stride=%lld is smaller than one slice's extent (%lld elements)",
+                   (long long)d->split_stride, (long long)(c_last + d->N));
+    }
 
     GemmParams p;
     p.A = reinterpret_cast<const __bf16*>(d->A);
@@ -952,8 +975,13 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
     p.kper = 0;
     p.split_stride = 0;
     p.trace = nullptr;
+#ifdef HK_DIAG
+    // diagnostic build only: HK_GEMM_DEBUG bit 1 = skip the epilogue, bit 2 = one K-tile per tile (wrong results by design)
     static const int dbg = getenv("HK_GEMM_DEBUG") ? atoi(getenv("HK_GEMM_DEBUG")) : 0;
     p.dbg = dbg;
+#else
+    p.dbg = 0;
+#endif
     static const int gm = getenv("HK_GEMM_GM") ? atoi(getenv("HK_GEMM_GM")) : 4;
     p.gm = gm < 1 ? 1 : gm;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -68,6 +68,25 @@ def barrier():
         dist.barrier()
 
 
+def ranks_seen(device) -> List[dict]:
+    """What every rank of the job reports about itself, gathered over the process group's own backend (RCCL on GPUs):
+    [{"rank", "local_rank", "device_count", "device_index"}] in rank order.  bench.py puts it into its JSON line so a
+    multi-GPU run shows that the collective really spanned N ranks on N distinct devices."""
+    rank, local_rank, world = env_world()
+    device = torch.device(device)
+    on_gpu = device.type == "cuda"
+    mine = torch.tensor([rank, local_rank, torch.cuda.device_count() if on_gpu else 0,
+                         device.index if on_gpu and device.index is not None else (torch.cuda.current_device() if on_gpu else -1)],
+                        dtype=torch.int64, device=device)
+    if not dist.is_initialized():
+        rows = mine.view(1, 4)
+    else:
+        rows = torch.empty(dist.get_world_size() * 4, dtype=torch.int64, device=device)   # flat: what gloo accepts too
+        dist.all_gather_into_tensor(rows, mine)
+        rows = rows.view(-1, 4)
+    return [dict(zip(("rank", "local_rank", "device_count", "device_index"), map(int, r))) for r in rows.cpu().tolist()]
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # Row f2: data-parallel gradient exchange of the stage-3 step (SURVEY.md §8e; the reference relies on
 # DistributedDataParallel's bucketed all-reduce, tasks/shared_utils.py:54-59).  The trainable parameters' gradients

@@ -384,11 +384,7 @@ class HipEncoderEngine:
         qscale = (64 ** -0.5) * LOG2E
 
         if run_vit:
-            ksv = 1      # the ViT's self-attention is never split (see key_splits_for)
-            akw = {}
-            if ksv > 1:
-                akw = dict(key_splits=ksv, o_part=P(plan.buf("attn_part", (B * ksv, N, D), bf16, dev)),
-                           lse_part=P(plan.buf("attn_lse", (B * ksv, Hv, N), f32, dev)))
+            # (the ViT's self-attention is never key-split: 304 workgroups at B = 1 already, see key_splits_for)
             # ---- ViT: patch-embed GEMM (+bias, + position table broadcast over the batch) ----
             # step 0 (patchify) and the table pointer are bound at run time
             xf32 = self.residual_dtype == torch.float32
@@ -459,6 +455,7 @@ class HipEncoderEngine:
         plan.vit_end = len(plan.steps)
         if run_qf:
             ksc = self.key_splits_for(B, Hq, nq, N)
+            plan.cross_key_splits = ksc
             ckw = {}
             if ksc > 1:
                 ckw = dict(key_splits=ksc, o_part=P(plan.buf("cattn_part", (B * ksc, nq, d), bf16, dev)),
@@ -498,7 +495,7 @@ class HipEncoderEngine:
                     self._gemm(plan, P(ab), w[o + "cq.w"], P(cq), B * nq, d, d, bias=P(w[o + "cq.b"]),
                                a_rows=qrows, c_rows=plain(d), scale_cols=d, scale=qscale)
                     self._attn(plan, P(cq), P(kvc) + ci * 2 * d * eb, P(kvc) + (ci * 2 + 1) * d * eb, P(cctx), B, Hq, nq, N,
-                               d, KVW, KVW, d, nq * d, N * KVW, N * KVW, nq * d)
+                               d, KVW, KVW, d, nq * d, N * KVW, N * KVW, nq * d, **ckw)
                     if sk_c > 1:
                         self._gemm(plan, P(cctx), w[o + "co.w"], P(parts_c), B * nq, d, d, bias=P(w[o + "co.b"]), residual=P(af),
                                    a_rows=plain(d), c_rows=plain(d), r_rows=qrows, out_f32=True, split_k=sk_c,

@@ -233,12 +233,14 @@ class HawkEyeEncoder(nn.Module):
     def __init__(self, cfg: EncoderConfig = EncoderConfig(), tokenizer=None, max_txt_len: int = 512,
                  out_dtype: torch.dtype = torch.float16, residual_dtype: torch.dtype = torch.bfloat16,
                  freeze_vit: bool = True, freeze_qformer: bool = True):
-        """freeze_vit / freeze_qformer: hawkeye_it.py:26-27 (both default True there; stage 3 trains with
-        freeze_qformer=False, scripts/train/config_7b_stage3.py).  The ViT has no backward on this path, so
-        freeze_vit=False is refused."""
+        """freeze_vit / freeze_qformer: hawkeye_it.py:26-27,82-99 (both default True there; stage 3 trains with
+        freeze_vit=True, freeze_qformer=False, scripts/train/config_7b_stage3.py:40-41; the eval config the two test
+        scripts load, configs/config.json:6-7, sets both False and then runs under model.eval() + torch.no_grad()).
+        freeze_vit=False constructs like the reference: the ViT parameters keep requires_grad=True and the ViT is
+        not pinned to eval mode.  Inference is the same launch sequence either way (the ViT has no dropout and
+        drop-path 0, vit.py:118-119, config.json:18); only a call that would have to produce a ViT GRADIENT (grad
+        mode on and a ViT parameter requiring grad) is refused: the path has no ViT backward."""
         super().__init__()
-        if not freeze_vit:
-            raise NotImplementedError("the HIP path keeps the ViT frozen (every shipped config sets freeze_vit=True)")
         self.cfg = cfg
         # registered first: Blip2Base.device is "device of the first parameter" (blip2.py:32-34)
         self.query_tokens = nn.Parameter(torch.zeros(1, cfg.num_query_token, cfg.qf_hidden))
@@ -271,12 +273,14 @@ class HawkEyeEncoder(nn.Module):
         self._drop_seed, self._drop_calls = 0, 0
         self._table_cache = {}
         # hawkeye_it.py:82-99
-        for prm in list(self.vision_encoder.parameters()) + list(self.vision_layernorm.parameters()):
-            prm.requires_grad = False
-        self.vision_encoder = self.vision_encoder.eval()
-        self.vision_encoder.train = disabled_train.__get__(self.vision_encoder)
-        self.vision_layernorm = self.vision_layernorm.eval()
-        self.vision_layernorm.train = disabled_train.__get__(self.vision_layernorm)
+        self.freeze_vit, self.freeze_qformer = bool(freeze_vit), bool(freeze_qformer)
+        if freeze_vit:
+            for prm in list(self.vision_encoder.parameters()) + list(self.vision_layernorm.parameters()):
+                prm.requires_grad = False
+            self.vision_encoder = self.vision_encoder.eval()
+            self.vision_encoder.train = disabled_train.__get__(self.vision_encoder)
+            self.vision_layernorm = self.vision_layernorm.eval()
+            self.vision_layernorm.train = disabled_train.__get__(self.vision_layernorm)
         if freeze_qformer:
             for prm in self.qformer.parameters():
                 prm.requires_grad = False
@@ -345,16 +349,25 @@ class HawkEyeEncoder(nn.Module):
 
     @classmethod
     def from_reference_config(cls, config, **kw):
-        """Build from the reference's model config dict (configs/config.json `model`)."""
+        """Build from the reference's model config dict: the `model` entry of configs/config.json (what tasks/test.py
+        :649-651 and tasks/test_recursive_grounding.py:497 load; freeze_vit = freeze_qformer = false, max_txt_len 512,
+        num_frames 32) or of scripts/train/config_7b_stage3.py:35-85 after its ${...} references are resolved
+        (freeze_vit True, freeze_qformer False, num_frames 12).  Keys are read with the defaults of
+        hawkeye_it.py:22-53 / vit.py:408-422; keys of the LLM half (llama_model_path, lora_*, prompt tokens) are
+        ignored."""
         ve = config["vision_encoder"]
         cfg = EncoderConfig(
             img_size=ve["img_size"], patch_size=ve["patch_size"], encoder_embed_dim=ve["encoder_embed_dim"],
             encoder_depth=ve["encoder_depth"], return_index=ve.get("return_index", -1),
-            encoder_num_heads=ve["encoder_num_heads"], num_frames=ve["num_frames"],
+            encoder_num_heads=ve["encoder_num_heads"], num_frames=int(ve["num_frames"]),
             num_query_token=config["num_query_token"], extra_num_query_token=config.get("extra_num_query_token", 32))
+        if config.get("low_resource", False):
+            raise NotImplementedError("low_resource=True (8-bit LLM + ViT on the CPU, hawkeye_it.py:29,213-223) is not "
+                                      "offered: the path has no CPU arithmetic")
         kw.setdefault("freeze_vit", config.get("freeze_vit", True))
         kw.setdefault("freeze_qformer", config.get("freeze_qformer", True))
-        m = cls(cfg, max_txt_len=config.get("max_txt_len", 32), **kw)
+        m = cls(cfg, max_txt_len=int(config.get("max_txt_len", 32)), **kw)
+        m.qformer_text_input = bool(config.get("qformer_text_input", True))                    # hawkeye_it.py:36
         m.qformer_hidden_dropout_prob = config.get("qformer_hidden_dropout_prob", 0.1)          # hawkeye_it.py:32-34
         m.qformer_attention_probs_dropout_prob = config.get("qformer_attention_probs_dropout_prob", 0.1)
         m.qformer_drop_path_rate = config.get("qformer_drop_path_rate", 0.1)
@@ -564,6 +577,12 @@ class HawkEyeEncoder(nn.Module):
         dropout = self.qformer.training
         need_grad = torch.is_grad_enabled() and self._any_requires_grad("qformer")
         train_path = dropout or need_grad
+        if not self.freeze_vit and torch.is_grad_enabled() and self._any_requires_grad("vit"):
+            raise NotImplementedError(
+                "this call would need a gradient for the ViT (grad mode is on and a vision_encoder / vision_layernorm "
+                "parameter requires grad): the HIP path has no ViT backward.  Stage 3 freezes the ViT "
+                "(scripts/train/config_7b_stage3.py:40); for inference call under model.eval() + torch.no_grad() as "
+                "tasks/test.py and tasks/test_recursive_grounding.py do, or set requires_grad=False on those parameters")
         if self.low_resource:
             raise NotImplementedError("low_resource (ViT in fp32 on the CPU, hawkeye_it.py:213-223) is not offered: the "
                                       "path has no CPU arithmetic; a 288 GB MI355X holds the 0.6 GB of ViT operands")

@@ -58,3 +58,19 @@ def test_bad_descriptors_are_rejected_with_text():
     assert lib.hk_layernorm(None, 0, None, None, None, None, None, None, 4, 64, 1e-6, None) == 1
     assert lib.hk_patchify_bf16(4096, 4096, 1, 1, 30, 32, 16, None) == 1
     assert "bad shape" in L.last_error()
+
+
+def test_product_library_carries_no_diagnostic_switches():
+    """HK_GEMM_TRACE (hipMalloc + hipStreamSynchronize + hipMemcpy inside the launch path) and
+    HK_GEMM_DEBUG (wrong results by design) are compiled only into the -DHK_DIAG build (`make diag`).  The shipped
+    library promises 'never allocates, frees or synchronises' (include/hawkeye_hip.h): check its strings and its
+    undefined dynamic symbols."""
+    import subprocess
+    from hawkeye_amd import lib as L
+    blob = open(L.LIB_PATH, "rb").read()
+    for name in (b"HK_GEMM_TRACE", b"HK_GEMM_DEBUG"):
+        assert name not in blob, name
+    syms = subprocess.run(["nm", "-D", "--undefined-only", L.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    used = {line.split()[-1].split("@")[0] for line in syms.splitlines() if line.strip()}
+    for banned in ("hipMalloc", "hipFree", "hipStreamSynchronize", "hipDeviceSynchronize", "hipMemcpy", "hipMallocAsync"):
+        assert banned not in used, banned

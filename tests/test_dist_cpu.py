@@ -36,6 +36,8 @@ def _worker(rank, world, port, total, q):
         full2 = hd.gather_outputs(local)
         ok = ok and torch.equal(full2, full)
     t = hd.max_over_ranks(1.0 + rank, "cpu")
+    seen = hd.ranks_seen("cpu")          # what bench.py reports as `ranks_seen`
+    ok = ok and [(e["rank"], e["local_rank"]) for e in seen] == [(i, i) for i in range(world)]
     hd.barrier()
     q.put((rank, bool(ok), t))
     torch.distributed.destroy_process_group()
@@ -174,3 +176,69 @@ def test_bucket_bounds_and_single_process_reducer():
     red.ready(9)
     red.finish()
     assert red.log == [(0, 8), (8, 10)] and torch.equal(g, torch.ones(10))      # no process group: values untouched
+
+
+def _stand_in_encode(frames, instruction):
+    """encode_frames stand-in: a [b, 4, 8] tensor that is a fixed function of each clip's bytes (so a clip's result does
+    not depend on which rank or micro-batch carried it)."""
+    b = frames.shape[0]
+    f = frames.reshape(b, -1).to(torch.float64)
+    feats = torch.stack([f.mean(1), f.std(1), f[:, ::97].sum(1), f[:, 5::1013].sum(1)], dim=1)
+    return (feats[:, :, None] * torch.arange(1, 9, dtype=torch.float64)).float(), False
+
+
+def _answer(example, turn, row, bound):
+    from hawkeye_amd.grounding import CHOICES
+    return CHOICES[(int(row.abs().sum().item()) + 3 * int(example) + turn) % 4]
+
+
+def _batcher_worker(rank, world, port, n_examples, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from hawkeye_amd import dist as hd
+    from hawkeye_amd.grounding import RecursiveGroundingBatcher, SyntheticFrameSource
+    hd.init("gloo")
+    examples = list(range(n_examples))
+    b = RecursiveGroundingBatcher(_stand_in_encode, SyntheticFrameSource(size=32, seed=5), _answer, "sys", max_turns=4,
+                                  num_segments=3, micro_batch=4, size=32, device="cpu", keep_outputs=True)
+    mine = b.run(examples, rank, world)
+    lo, hi = hd.shard_range(n_examples, rank, world)
+    ok = sorted(mine) == examples[lo:hi]                       # --start-idx/--end-idx block of this rank
+    # the only exchange of the path: all_gather of the first turn's outputs, uneven counts, in example order
+    counts = [hd.shard_range(n_examples, r, world)[1] - hd.shard_range(n_examples, r, world)[0] for r in range(world)]
+    local = torch.stack([mine[e]["outputs"][0] for e in examples[lo:hi]]) if hi > lo else torch.zeros(0, 4, 8)
+    full = hd.gather_outputs(local, counts)
+    hd.barrier()
+    q.put((rank, bool(ok), {e: (r["bound"], r["answers"]) for e, r in mine.items()}, full))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gloo_recursive_grounding_batcher_equals_single_rank():
+    """BASELINE config 3 shards by EXAMPLE (tasks/test_recursive_grounding.py:481-482): both ranks of a gloo
+    group drive RecursiveGroundingBatcher.run(examples, rank, world); the union of their results must equal the
+    single-rank run, and gather_outputs with uneven counts must reassemble the outputs in example order."""
+    from hawkeye_amd.grounding import RecursiveGroundingBatcher, SyntheticFrameSource
+    n = 11                                                     # 6 + 5: uneven shards, micro-batches of 4 + tail
+    single = RecursiveGroundingBatcher(_stand_in_encode, SyntheticFrameSource(size=32, seed=5), _answer, "sys", max_turns=4,
+                                       num_segments=3, micro_batch=4, size=32, device="cpu", keep_outputs=True).run(list(range(n)))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_batcher_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _, _ in res)
+    union = {}
+    for _, _, part, _ in res:
+        assert not (set(part) & set(union))
+        union.update(part)
+    assert union == {e: (r["bound"], r["answers"]) for e, r in single.items()}
+    assert any(len(a) > 1 for _, a in union.values()) and any(a[-1] == "throughout" for _, a in union.values())
+    want = torch.stack([single[e]["outputs"][0] for e in range(n)])
+    for _, _, _, full in res:
+        assert torch.equal(full, want)

@@ -449,3 +449,65 @@ def test_default_output_dtype_and_errors():
         m.encode_img(image, "what happens in the video?")
     with pytest.raises(RuntimeError, match="positions"):
         m.encode_img(W.make_clip(1, 3, SMALL.img_size, 1).to(DEV), (ids, mask))
+
+
+def test_unfrozen_build_runs_inference_with_the_same_bits_as_the_frozen_build():
+    """configs/config.json:6-7 (what tasks/test.py:649-651 and tasks/test_recursive_grounding.py:497 load) sets
+    freeze_vit = freeze_qformer = false; both scripts then call model.eval() and run encode_img under torch.no_grad().
+    That build must construct (hawkeye_it.py:82-99: parameters simply keep requires_grad=True) and give the frozen
+    build's bits; only a call that would need a ViT gradient is refused."""
+    cfg, seed, B, T = SMALL, 41, 2, 2
+    sd = W.make_state_dict(cfg, seed)
+    image = W.make_clip(B, T, cfg.img_size, seed).to(DEV)
+    ids, mask = W.make_instruction_ids(B, 5, cfg.qf_vocab, seed, ragged=True)
+    table = posembed.video_pos_embed(T, cfg.patches_per_frame, cfg.encoder_embed_dim, cfg.ckpt_num_frame)
+    outs = []
+    for frozen in (True, False):
+        m = HawkEyeEncoder(cfg, out_dtype=torch.float32, freeze_vit=frozen, freeze_qformer=frozen)
+        m.load_state_dict(sd, strict=True)
+        m = m.to(DEV).eval()
+        m.vision_encoder.encoder.pos_embed = table
+        assert all(p.requires_grad != frozen for n, p in m.named_parameters()
+                   if n.startswith(("vision_encoder.", "vision_layernorm.", "qformer.")))
+        with torch.no_grad():
+            outs.append(m.encode_img(image, (ids, mask))[0].clone())
+        assert m._train_engine is None                       # eval() + no_grad(): the inference engine
+    assert torch.equal(outs[0], outs[1])
+    with torch.enable_grad():
+        with pytest.raises(NotImplementedError, match="ViT"):
+            m.encode_img(image, (ids, mask))
+        # the reference's own remedy for a frozen ViT (hawkeye_it.py:84-89) lifts the refusal: stage-3 style call
+        for n, p in m.named_parameters():
+            if n.startswith(("vision_encoder.", "vision_layernorm.")):
+                p.requires_grad = False
+        out, _ = m.encode_img(image, (ids, mask))
+        assert out.requires_grad and _cos(out.detach(), outs[0]) > 0.9999
+
+
+def test_cross_attention_key_split_is_applied_in_the_engine_and_matches_unsplit(golden_dir, monkeypatch):
+    """the engine built the key-split buffers but never passed them to the cross-attention launch.  At
+    B = 1, T = 12 (what the eval scripts run) the plan's cross-attention descriptors must carry key_splits > 1, the
+    result must match the unsplit launch (HK_ATTN_SPLIT=0) and the golden."""
+    from hawkeye_amd import lib as L
+    g = np.load(os.path.join(golden_dir, "full_T12_B2.npz"))
+    T, seed = int(g["T"]), int(g["seed"])
+    m = _model(FULL, seed, T)
+    image = W.make_clip(2, T, FULL.img_size, seed).to(DEV)[:1]
+    ids, mask = torch.from_numpy(g["input_ids"])[:1], torch.from_numpy(g["text_mask"])[:1]
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("HK_ATTN_SPLIT", flag)
+        m._engine and m._engine.plans.clear()
+        outs[flag] = m.encode_img(image, (ids, mask))[0].clone()
+        plan = m._engine.plans[(1, T, ids.shape[1])]
+        cross = [d for d in plan.keep if isinstance(d, L.HkAttnDesc) and d.Nq == 96 and d.Nk == T * 196]
+        assert len(cross) == 6
+        if flag == "1":
+            assert plan.cross_key_splits > 1 and all(d.key_splits == plan.cross_key_splits and d.o_part and d.lse_part
+                                                     for d in cross)
+        else:
+            assert plan.cross_key_splits == 1 and all(d.key_splits <= 1 for d in cross)
+    c = _cos(outs["1"], outs["0"])
+    print(f"[parity] key-split cross-attention vs unsplit: cosine = {c:.7f}")
+    assert c > 0.99999
+    _check("full_T12_B2[clip 0].out (key split)", outs["1"], g["out"][:1])

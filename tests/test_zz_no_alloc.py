@@ -21,11 +21,20 @@ def _both(x: torch.Tensor):
     out = torch.empty(Cc, dtype=torch.float32, device=x.device)
     L.check(lib.hk_colsum(x.data_ptr(), dt, x.stride(0), R, Cc, ref.data_ptr(), ws.data_ptr(), stream), "hk_colsum")
     torch.cuda.synchronize()
-    before = torch.cuda.memory_allocated()
+    # torch's counter sees only torch's caching allocator; the driver-level free memory also sees a hipMalloc / hipFree
+    # made by the library itself.  The first call on a device does the one-time symbol lookup, so the driver-level
+    # comparison is made from the second call on.
+    before, free_before = torch.cuda.memory_allocated(), torch.cuda.mem_get_info()[0]
     L.check(lib.hk_colsum_static(x.data_ptr(), dt, x.stride(0), R, Cc, out.data_ptr(), stream), "hk_colsum_static")
     torch.cuda.synchronize()
     assert torch.cuda.memory_allocated() == before
+    if _both.calls > 0:
+        assert torch.cuda.mem_get_info()[0] == free_before, "device memory changed across an hk_colsum_static call"
+    _both.calls += 1
     return out, ref
+
+
+_both.calls = 0
 
 
 def test_static_scratch_colsum_matches_workspace_colsum_twice():

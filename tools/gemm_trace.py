@@ -5,6 +5,9 @@ import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 path = os.environ.setdefault("HK_GEMM_TRACE", "/tmp/gemm_trace.bin")
+# the trace switch exists only in the diagnostic build (make -C hawkeye_amd/csrc diag)
+os.environ.setdefault("HK_LIB_PATH", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                  "hawkeye_amd", "libhawkeye_hip_diag.so"))
 from hawkeye_amd import ops
 DEV = "cuda:0"
 # usage: gemm_trace.py [N K [res16|gelu]]
