@@ -180,3 +180,43 @@ def make_prompt(cfg: LlmConfig, B: int, S: int, n_video: int, seed: int, ragged:
             mask[b, S - n_pad:] = 0
             ids[b, S - n_pad:] = 2                      # pad = eos (hawkeye_it.py:104)
     return ids, mask
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# "Massive activation" statistics (missing item 3).  A trained UMT-L, unlike an init-law model, carries a few
+# residual-stream channels two orders of magnitude above the row RMS, LayerNorm gains far from 1 and attention heads with
+# sharply peaked logits -- exactly where a bf16 residual stream and a folded LayerNorm lose bits.  Real checkpoints are
+# not available offline, so the statistics are produced by a deterministic edit of the seeded state dict; the same edit
+# goes through the reference modules (oracle/make_goldens.py outlier -> tests/golden/full_T8_outlier.npz).
+# ---------------------------------------------------------------------------------------------------------------------
+OUTLIER_CHANNELS = (77, 412, 901)      # residual channels driven to ~100x the row RMS
+OUTLIER_GAIN_CHANNELS = (5, 600)       # norm1.weight entries x 20 in every block
+OUTLIER_HEAD = 3                       # the attention head whose logits are spread > 30 (every 4th block)
+
+
+def make_outlier_state_dict(cfg: EncoderConfig, seed: int = 0, depth_in_ckpt: bool = False):
+    sd = make_state_dict(cfg, seed, depth_in_ckpt)
+    D, hd = cfg.encoder_embed_dim, cfg.encoder_embed_dim // cfg.encoder_num_heads
+    p = "vision_encoder.encoder."
+    nblk = cfg.encoder_depth if depth_in_ckpt else cfg.run_depth
+    ch = [c % D for c in OUTLIER_CHANNELS]
+    sign = (1.0, -1.0, 1.0)
+    # the patch-embed output of these weights has row RMS ~0.9 over the remaining channels (unit-normal pixels,
+    # kaiming-uniform Conv3d) and the blocks grow it to ~4; the channels start at +-100 and each fc2 bias pushes them 15
+    # further (~450 after block 22), which keeps them at ~100x the RMS of the remaining channels through all 23 blocks
+    for c, s in zip(ch, sign):
+        sd[p + "patch_embed.proj.bias"][c] += 100.0 * s
+    for i in range(nblk):
+        b = f"{p}blocks.{i}."
+        for c, s in zip(ch, sign):
+            sd[b + "mlp.fc2.bias"][c] += 15.0 * s
+        for c in OUTLIER_GAIN_CHANNELS:
+            sd[b + "norm1.weight"][c % D] *= 20.0
+        if i % 4 == 1:
+            # one head with sharply peaked attention: its q and k rows x 12 => logits x 144
+            h = OUTLIER_HEAD % cfg.encoder_num_heads
+            w = sd[b + "attn.qkv.weight"]
+            w[h * hd:(h + 1) * hd] *= 12.0
+            w[D + h * hd:D + (h + 1) * hd] *= 12.0
+            sd[b + "attn.q_bias"][h * hd:(h + 1) * hd] *= 12.0
+    return sd

@@ -24,6 +24,7 @@ Usage:  python oracle/make_goldens.py            (writes tests/golden/)
         python oracle/make_goldens.py llm_leftpad  (round 2: the left-padded prefill fixture)
         python oracle/make_goldens.py round2     (only full_T12_B2 + small_video_notext, added in round 2)
         python oracle/make_goldens.py train      (only the row f2 training fixture)
+        python oracle/make_goldens.py outlier    (round 3: full_T8_outlier, massive-activation weight statistics)
 """
 import importlib.machinery
 import importlib.util
@@ -187,22 +188,27 @@ def reference_encode_img_grad(m, image, input_ids, text_mask, stages=None):
     return out, use_image
 
 
-def digest(t: torch.Tensor):
-    """Size-independent summary + a fixed slice of a stage tensor [B, rows, cols]."""
+def digest(t: torch.Tensor, extra_cols=()):
+    """Size-independent summary + a fixed slice of a stage tensor [B, rows, cols].  extra_cols: columns added to the
+    evenly spaced ones (the outlier fixture samples its outlier channels)."""
     t = t.detach().float()
     flat = t.reshape(-1, t.shape[-1])
     r = min(8, flat.shape[0])
     c = min(16, flat.shape[1])
     rows = np.linspace(0, flat.shape[0] - 1, r).astype(np.int64)
     cols = np.linspace(0, flat.shape[1] - 1, c).astype(np.int64)
+    if len(extra_cols):
+        cols = np.unique(np.concatenate([cols, np.asarray(extra_cols, dtype=np.int64)]))
     sl = flat[torch.from_numpy(rows)][:, torch.from_numpy(cols)].numpy()
     return dict(shape=np.array(t.shape, dtype=np.int64), mean=np.float64(t.double().mean().item()),
                 std=np.float64(t.double().std().item()), l2=np.float64(t.double().norm().item()),
                 rows=rows, cols=cols, slice=sl)
 
 
-def run_case(name, cfg: EncoderConfig, B, T, Lt, seed, ragged, full_tensors, ref_vit, ref_qf, outdir):
-    sd = W.make_state_dict(cfg, seed)
+def run_case(name, cfg: EncoderConfig, B, T, Lt, seed, ragged, full_tensors, ref_vit, ref_qf, outdir, outlier=False):
+    # outlier=True: the seeded weights with "massive activation" statistics (hawkeye_amd/weights.py
+    # make_outlier_state_dict), pushed through the same reference modules
+    sd = W.make_outlier_state_dict(cfg, seed) if outlier else W.make_state_dict(cfg, seed)
     m = build_reference(cfg, sd, ref_vit, ref_qf)
     image = W.make_clip(B, T, cfg.img_size, seed)
     ids, mask = W.make_instruction_ids(B, Lt, cfg.qf_vocab, seed, ragged) if Lt > 0 else (None, None)
@@ -219,6 +225,8 @@ def run_case(name, cfg: EncoderConfig, B, T, Lt, seed, ragged, full_tensors, ref
     out, use_image = reference_encode_img(m, image, ids, mask, stages)
     rec = dict(B=np.int64(B), T=np.int64(T), Lt=np.int64(Lt), seed=np.int64(seed), ragged=np.int64(ragged),
                use_image=np.int64(use_image))
+    if outlier:
+        rec["outlier"] = np.int64(1)
     if Lt > 0:
         rec.update(input_ids=ids.numpy(), text_mask=mask.numpy())
     if full_tensors:
@@ -228,7 +236,10 @@ def run_case(name, cfg: EncoderConfig, B, T, Lt, seed, ragged, full_tensors, ref
     else:
         rec["out"] = out.numpy().astype(np.float32)
         for k, v in stages.items():
-            for dk, dv in digest(v).items():
+            extra = ()
+            if outlier and v.shape[-1] == cfg.encoder_embed_dim:
+                extra = tuple(W.OUTLIER_CHANNELS) + tuple(W.OUTLIER_GAIN_CHANNELS)
+            for dk, dv in digest(v, extra).items():
                 rec[f"digest.{k}.{dk}"] = dv
     path = os.path.join(outdir, name + ".npz")
     np.savez_compressed(path, **rec)
@@ -469,6 +480,12 @@ def main():
         train_goldens(ref_vit, ref_qf, outdir)
         return
     ref_vit, ref_qf = _import_reference()
+    if sys.argv[1:] == ["outlier"]:
+        # round 3: trained-model statistics (three residual channels at ~100x the row RMS, two norm1 gains x 20, one
+        # head with logits spread > 30 in blocks 1, 5, 9, ...) through the reference modules
+        run_case("full_T8_outlier", FULL, B=1, T=8, Lt=12, seed=31, ragged=False, full_tensors=False,
+                 ref_vit=ref_vit, ref_qf=ref_qf, outdir=outdir, outlier=True)
+        return
     if sys.argv[1:] == ["round2"]:
         # added in round 2 (the fixtures of round 1 are left as committed): the shipped default frame count
         # (scripts/train/config_7b_stage3.py:13, tasks/test.py:584) with a ragged text mask, and the

@@ -2,7 +2,8 @@
 vs the committed reference-module goldens and vs the oracle on the same seeded inputs.
 
 Tolerance (BASELINE.json north_star): bf16 matmuls, fp32 LN/softmax/accumulate =>
-cosine >= 0.999 against the fp32 reference; max |err| / max |ref| is printed and bounded at 5e-2.
+cosine >= 0.999 against the fp32 reference; max |err| / max |ref| is printed and bounded at 2.5e-2
+(measured 2e-3 ... 1.8e-2, profiles/r02_parity.txt, profiles/r03_parity.txt).
 """
 import os
 
@@ -26,7 +27,7 @@ from hawkeye_amd.model import HawkEyeEncoder  # noqa: E402
 
 DEV = "cuda:0"
 COS_MIN = 0.999
-REL_MAX = 5e-2
+REL_MAX = 2.5e-2
 
 
 def _cos(a, b):
@@ -511,3 +512,44 @@ def test_cross_attention_key_split_is_applied_in_the_engine_and_matches_unsplit(
     print(f"[parity] key-split cross-attention vs unsplit: cosine = {c:.7f}")
     assert c > 0.99999
     _check("full_T12_B2[clip 0].out (key split)", outs["1"], g["out"][:1])
+
+
+@pytest.mark.parametrize("residual_dtype,epi_stats", [(torch.bfloat16, "1"), (torch.bfloat16, "0"), (torch.float32, "1")])
+def test_outlier_statistics_golden(golden_dir, monkeypatch, residual_dtype, epi_stats):
+    """every other fixture uses init-law weights.  full_T8_outlier pushes weights with trained-model
+    statistics through the reference modules: three residual channels at ~100x the row RMS (up to +-445 after block
+    22), two norm1 gains x 20, one head whose logits spread by 20-115 in blocks 1, 5, 9, ... -- where a bf16 residual
+    stream rounded once per update, the folded-LayerNorm mean cancellation and the no-running-maximum softmax path
+    would lose bits first.  Checked for both residual stream types and for both sources of the LayerNorm statistics
+    (HK_EPI_STATS: GEMM epilogue sums / a pass over the stream); the ViT slices are also checked on the NON-outlier
+    columns alone, whose scale is 100x smaller than the slice maximum."""
+    monkeypatch.setenv("HK_EPI_STATS", epi_stats)
+    g = np.load(os.path.join(golden_dir, "full_T8_outlier.npz"))
+    B, T, seed = int(g["B"]), int(g["T"]), int(g["seed"])
+    m = HawkEyeEncoder(FULL, out_dtype=torch.float32, residual_dtype=residual_dtype)
+    m.load_state_dict(W.make_outlier_state_dict(FULL, seed), strict=True)
+    m = m.to(DEV).eval()
+    m.vision_encoder.encoder.pos_embed = posembed.video_pos_embed(T, FULL.patches_per_frame, FULL.encoder_embed_dim,
+                                                                  FULL.ckpt_num_frame)
+    image = W.make_clip(B, T, FULL.img_size, seed).to(DEV)
+    ids, mask = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["text_mask"])
+    out, _ = m.encode_img(image, (ids, mask))
+    assert m._engine.epi_stats == (epi_stats == "1")
+    tag = f"outlier[{str(residual_dtype).split('.')[-1]},epi_stats={epi_stats}]"
+    _check(f"{tag}.out", out, g["out"])
+    ws = m._engine.plans[(B, T, ids.shape[1])].ws
+    for stage, buf in (("vision_layernorm", ws["xn"].float()), (f"vit_block_{FULL.run_depth - 1}", ws["x"].float())):
+        rows = torch.from_numpy(g[f"digest.{stage}.rows"]).to(DEV)
+        cols = g[f"digest.{stage}.cols"]
+        got = buf[rows][:, torch.from_numpy(cols).to(DEV)]
+        _check(f"{tag}.{stage}.slice", got, g[f"digest.{stage}.slice"])
+        rest = np.nonzero(~np.isin(cols, W.OUTLIER_CHANNELS))[0]
+        assert len(rest) >= 16
+        _check(f"{tag}.{stage}.slice[non-outlier columns]", got[:, torch.from_numpy(rest).to(DEV)],
+               g[f"digest.{stage}.slice"][:, rest])
+    S = 96 + ids.shape[1]
+    stage = f"qf_layer_{FULL.qf_layers - 1}"
+    rows = g[f"digest.{stage}.rows"]
+    keep = np.nonzero(rows % S < 96)[0]
+    cols = torch.from_numpy(g[f"digest.{stage}.cols"]).to(DEV)
+    _check(f"{tag}.{stage}.query_rows", ws["hf"][torch.from_numpy(rows[keep]).to(DEV)][:, cols], g[f"digest.{stage}.slice"][keep])
