@@ -20,6 +20,12 @@
 #include <stdlib.h>
 #include "hk_common.h"
 
+#ifndef HK_DUO_PF
+#define HK_DUO_PF 1   // residual prefetch distance of the duo kernel's in-place epilogue (rounds)
+#endif
+#ifndef HK_GEMM_DUO_DEFAULT
+#define HK_GEMM_DUO_DEFAULT 0
+#endif
 // Diagnostic switches (timing-only kernels, phase stamps) exist only in the -DHK_DIAG build (make diag)
 #ifdef HK_DIAG
 #define HK_DBG(p) ((p).dbg)
@@ -174,6 +180,232 @@ __device__ __forceinline__ void tile_coords(int lid, int nbm, int nbn, int gm_, 
 __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
     const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
+// ---- epilogue of one 128x64 wave sub-tile (no workgroup barrier inside; LDS regions private to the wave) ----
+// Shared by the persistent 256x256 kernel (8 waves) and the two-workgroups-per-CU 256x128 kernel (4 waves): both give a
+// wave 128 rows x 64 columns in the same accumulator layout.  `stg`: the wave's 4 KB transpose slab; `aux`: where the
+// main loop staged the epilogue operands (row statistics at +0, bias at +1024, column sums of W at +1280; the 256x256
+// kernel keeps them in the slab itself, they are read into registers before the first transpose overwrites them).
+// The accumulator layout (lane = 1 row x 4 columns of a 16x16 tile) would store 32-byte pieces of
+// 16 rows per instruction; instead 16 (fp32) / 32 (bf16) rows at a time go through LDS, XOR-swizzled,
+// and leave as whole 256 / 128-byte row segments, 16 bytes per lane.  The fp32 residual is read the
+// same way.  Bias, column scale and GELU are applied on the accumulator layout, before LDS.
+#ifndef HK_EPI_PF
+#define HK_EPI_PF 3
+#endif
+template <int EPI, int PF_ROUNDS = HK_EPI_PF>
+__device__ __forceinline__ void pp_epilogue(const GemmParams& p, f32x4 (&acc)[2][2][4][2], char* stg, const char* aux,
+                                            const int lane, const int wm, const int wn, const int m0, const int n0) {
+    if (HK_DBG(p) & 1) {  // dbg 1: timing-only build, no epilogue (accumulators kept live)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[a][b][i][j]));
+        return;
+    }
+    // bias of the wave's 64 columns: staged into the slab (bytes 1024..1279) by one 4-byte LDS-DMA at the start of
+    // the tile (main loop below) -- a global load here would be the youngest vector-memory operation of the wave, and
+    // waiting for it would also wait for every operand load of the next tile already in flight.
+    f32x4 bias[2][2];
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            bias[nh][j] = p.bias != nullptr
+                              ? *reinterpret_cast<const f32x4*>(aux + 1024 + (nh * 32 + j * 16 + (lane >> 4) * 4) * 4)
+                              : f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr bool FOLD = EPI == 3;
+    float rs[2][4], rm[2][4];
+    f32x4 cc[2][2];
+    if (FOLD) {
+        typedef __attribute__((ext_vector_type(2))) float f32x2s;
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // (mean, rstd) of row mh*64 + i*16 + (lane & 15) of the wave's 128: staged by the main loop
+                const f32x2s st = *reinterpret_cast<const f32x2s*>(aux + (mh * 64 + i * 16 + (lane & 15)) * 8);
+                rs[mh][i] = st[1];
+                rm[mh][i] = st[1] * st[0];
+            }
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)   // column sums of W: staged like the bias, slab bytes 1280..1535
+                cc[nh][j] = *reinterpret_cast<const f32x4*>(aux + 1280 + (nh * 32 + j * 16 + (lane >> 4) * 4) * 4);
+    }
+    auto pre = [&](f32x4 v, int nh, int j, int mh, int i) {
+        const int n = n0 + wn * 64 + nh * 32 + j * 16 + (lane >> 4) * 4;
+        if (FOLD) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                v[e] = __builtin_fmaf(v[e], rs[mh][i], __builtin_fmaf(-rm[mh][i], cc[nh][j][e], bias[nh][j][e]));
+        } else {
+            v += bias[nh][j];
+        }
+        if (p.scale_cols != 0 && n < p.scale_cols) v *= p.scale;  // uniform test first: most GEMMs scale nothing
+        if (p.act == HK_ACT_GELU_ERF) v = (EPI == 0 || EPI == 3 || !p.out_f32) ? gelu_erf4_bf16dst(v) : gelu_erf4(v);
+        return v;
+    };
+    const int mw = m0 + wm * 128;  // first row / column of this wave's sub-tile
+    const int nw = n0 + wn * 64;
+    const int r16 = lane & 15, g4 = lane >> 4;
+    if (EPI == 0 || EPI == 3) {
+        // bf16 out, no residual: 32 rows x 128 B per round; 16-B chunk c of row r lives at chunk c ^ (r & 7)
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2) {
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const f32x4 v = pre(acc[mh][nh][i2 * 2 + ii][j], nh, j, mh, i2 * 2 + ii);
+                            u32x2 o;
+                            o[0] = pack_bf16x2(v[0], v[1]);
+                            o[1] = pack_bf16x2(v[2], v[3]);
+                            const int row = ii * 16 + r16;
+                            const int ch = nh * 4 + j * 2 + (g4 >> 1);
+                            *reinterpret_cast<u32x2*>(stg + row * 128 + ((ch ^ (row & 7)) << 4) + (g4 & 1) * 8) = o;
+                        }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int row = it * 8 + (lane >> 3), ch = lane & 7;
+                    const u32x4 o = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((ch ^ (row & 7)) << 4));
+                    const int m = mw + mh * 64 + i2 * 32 + row, n = nw + ch * 8;
+                    // streaming output (qkv, hid, cross K/V: hundreds of MB read once by the next kernel): non-temporal
+                    // stores measured -1.5 % step time in situ; the in-place residual stream and the attention
+                    // output, which are re-read at once, measured no gain and keep plain stores
+                    if (m < p.M && n < p.N)
+                        __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(p.C) + p.c.off(m) + n));
+                }
+            }
+    } else {
+        // fp32 staging, 16 rows x 256 B per round; 16-B chunk c of row r lives at chunk c ^ r.  After
+        // the transpose a lane owns 4 consecutive columns of rows 4 it + g4: the residual (fp32 or bf16,
+        // possibly the output buffer itself) is read and the result stored as whole row segments, rounded
+        // once.  The residual of round k+1 is requested before the stores of round k are issued, so no
+        // round waits for a full memory round trip behind its predecessor's stores.
+        if (EPI == 2 || EPI == 4) {
+            // bf16 residual stream updated in place: a lane owns 8 consecutive columns (16 B of bf16)
+            // of rows 8 it + (lane >> 3); two staged fp32 chunks + one 16-B residual load per store.
+            // The residual rows of round r + PF are requested before round r is staged; the loads are unconditional
+            // (row clamped, N is a multiple of 256 here) so the compiler can count its waits instead of draining
+            // the queue.  HK_EPI_PF (compile time): prefetch distance in rounds.
+            constexpr int PF = PF_ROUNDS;
+            u32x4 rr[PF + 1][2];
+            auto res_load8 = [&](int rnd, u32x4(&dst)[2]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int m = min(mw + rnd * 16 + it * 8 + (lane >> 3), p.M - 1), n = nw + (lane & 7) * 8;
+                    dst[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const __bf16*>(p.res) + p.r.off(m) + n);
+                }
+            };
+#pragma unroll
+            for (int q = 0; q < PF; ++q) res_load8(q, rr[q]);
+#pragma unroll
+            for (int rnd = 0; rnd < 8; ++rnd) {
+                const int mh = rnd >> 2, i = rnd & 3;
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int ch = nh * 8 + j * 4 + g4;
+                        *reinterpret_cast<f32x4*>(stg + r16 * 256 + ((ch ^ r16) << 4)) = pre(acc[mh][nh][i][j], nh, j, mh, i);
+                    }
+                if (rnd + PF < 8) res_load8(rnd + PF, rr[(rnd + PF) % (PF + 1)]);
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int row = it * 8 + (lane >> 3), c8 = lane & 7;
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(stg + row * 256 + (((2 * c8) ^ row) << 4));
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(stg + row * 256 + (((2 * c8 + 1) ^ row) << 4));
+                    const int m = mw + rnd * 16 + row, n = nw + c8 * 8;
+                    const u32x4 r = rr[rnd % (PF + 1)][it];
+                    const float v0 = a[0] + bf16_lo(r[0]), v1 = a[1] + bf16_hi(r[0]), v2 = a[2] + bf16_lo(r[1]),
+                                v3 = a[3] + bf16_hi(r[1]), v4 = b[0] + bf16_lo(r[2]), v5 = b[1] + bf16_hi(r[2]),
+                                v6 = b[2] + bf16_lo(r[3]), v7 = b[3] + bf16_hi(r[3]);
+                    u32x4 o;
+                    o[0] = pack_bf16x2(v0, v1);
+                    o[1] = pack_bf16x2(v2, v3);
+                    o[2] = pack_bf16x2(v4, v5);
+                    o[3] = pack_bf16x2(v6, v7);
+                    if (EPI == 4) {
+                        // LayerNorm statistics of the updated residual stream, for the GEMM that consumes it with
+                        // the norm folded in: (sum, sum of squares) of this wave's 64 columns of the row -- of the
+                        // bf16 values as STORED, the ones the consumer multiplies: with the mean taken from the
+                        // unrounded sums the folded mean term would not cancel exactly against the MFMA's
+                        const float w0 = bf16_lo(o[0]), w1 = bf16_hi(o[0]), w2 = bf16_lo(o[1]), w3 = bf16_hi(o[1]),
+                                    w4 = bf16_lo(o[2]), w5 = bf16_hi(o[2]), w6 = bf16_lo(o[3]), w7 = bf16_hi(o[3]);
+                        float s1 = ((w0 + w1) + (w2 + w3)) + ((w4 + w5) + (w6 + w7));
+                        float s2 = w0 * w0;
+                        s2 = __builtin_fmaf(w1, w1, s2);
+                        s2 = __builtin_fmaf(w2, w2, s2);
+                        s2 = __builtin_fmaf(w3, w3, s2);
+                        s2 = __builtin_fmaf(w4, w4, s2);
+                        s2 = __builtin_fmaf(w5, w5, s2);
+                        s2 = __builtin_fmaf(w6, w6, s2);
+                        s2 = __builtin_fmaf(w7, w7, s2);
+                        s1 = sum8_dpp(s1);
+                        s2 = sum8_dpp(s2);
+                        if (c8 == 0 && m < p.M) {
+                            typedef __attribute__((ext_vector_type(2))) float f32x2s;
+                            *reinterpret_cast<f32x2s*>(p.row_part + ((int64_t)m * (p.N >> 6) + (nw >> 6)) * 2) = f32x2s{s1, s2};
+                        }
+                    }
+                    if (m < p.M && n < p.N)
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(p.C) + p.c.off(m) + n) = o;
+                }
+            }
+            return;
+        }
+        f32x4 rcur[4], rnxt[4];
+        auto res_load = [&](int rnd, f32x4(&rr)[4]) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int m = mw + rnd * 16 + it * 4 + g4, n = nw + r16 * 4;
+                rr[it] = (m < p.M && n < p.N) ? load_res4(p, p.r.off(m) + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        if (p.res) res_load(0, rcur);
+#pragma unroll
+        for (int rnd = 0; rnd < 8; ++rnd) {
+            const int mh = rnd >> 2, i = rnd & 3;
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int ch = nh * 8 + j * 4 + g4;
+                    *reinterpret_cast<f32x4*>(stg + r16 * 256 + ((ch ^ r16) << 4)) = pre(acc[mh][nh][i][j], nh, j, mh, i);
+                }
+            if (p.res && rnd < 7) res_load(rnd + 1, rnxt);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = it * 4 + g4, ch = r16;
+                f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * 256 + ((ch ^ row) << 4));
+                const int m = mw + rnd * 16 + row, n = nw + ch * 4;
+                if (m < p.M && n < p.N) {
+                    if (p.res) v += rcur[it];
+                    if (p.out_f32) {
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + p.c.off(m) + n) = v;
+                    } else {
+                        u32x2 o;
+                        o[0] = pack_bf16x2(v[0], v[1]);
+                        o[1] = pack_bf16x2(v[2], v[3]);
+                        *reinterpret_cast<u32x2*>(reinterpret_cast<__bf16*>(p.C) + p.c.off(m) + n) = o;
+                    }
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) rcur[it] = rnxt[it];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -341,226 +573,8 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
         HK_BAR();                                                                                           \
     } while (0)
 
-    // ---- epilogue of one tile (no workgroup barrier inside; LDS region private to the wave) ----
-    // The accumulator layout (lane = 1 row x 4 columns of a 16x16 tile) would store 32-byte pieces of
-    // 16 rows per instruction; instead 16 (fp32) / 32 (bf16) rows at a time go through LDS, XOR-swizzled,
-    // and leave as whole 256 / 128-byte row segments, 16 bytes per lane.  The fp32 residual is read the
-    // same way.  Bias, column scale and GELU are applied on the accumulator layout, before LDS.
     char* stg = smem + 2 * BUF * 2 + wave * 4096;
-    auto epilogue = [&](int m0, int n0) {
-        if (HK_DBG(p) & 1) {  // dbg 1: timing-only build, no epilogue (accumulators kept live)
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[a][b][i][j]));
-            return;
-        }
-        // bias of the wave's 64 columns: staged into the slab (bytes 1024..1279) by one 4-byte LDS-DMA at the start of
-        // the tile (main loop below) -- a global load here would be the youngest vector-memory operation of the wave, and
-        // waiting for it would also wait for every operand load of the next tile already in flight.
-        f32x4 bias[2][2];
-#pragma unroll
-        for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                bias[nh][j] = p.bias != nullptr
-                                  ? *reinterpret_cast<const f32x4*>(stg + 1024 + (nh * 32 + j * 16 + (lane >> 4) * 4) * 4)
-                                  : f32x4{0.f, 0.f, 0.f, 0.f};
-        constexpr bool FOLD = EPI == 3;
-        float rs[2][4], rm[2][4];
-        f32x4 cc[2][2];
-        if (FOLD) {
-            typedef __attribute__((ext_vector_type(2))) float f32x2s;
-#pragma unroll
-            for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    // (mean, rstd) of row mh*64 + i*16 + (lane & 15) of the wave's 128: staged by the main loop
-                    const f32x2s st = *reinterpret_cast<const f32x2s*>(stg + (mh * 64 + i * 16 + (lane & 15)) * 8);
-                    rs[mh][i] = st[1];
-                    rm[mh][i] = st[1] * st[0];
-                }
-#pragma unroll
-            for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)   // column sums of W: staged like the bias, slab bytes 1280..1535
-                    cc[nh][j] = *reinterpret_cast<const f32x4*>(stg + 1280 + (nh * 32 + j * 16 + (lane >> 4) * 4) * 4);
-        }
-        auto pre = [&](f32x4 v, int nh, int j, int mh, int i) {
-            const int n = n0 + wn * 64 + nh * 32 + j * 16 + (lane >> 4) * 4;
-            if (FOLD) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    v[e] = __builtin_fmaf(v[e], rs[mh][i], __builtin_fmaf(-rm[mh][i], cc[nh][j][e], bias[nh][j][e]));
-            } else {
-                v += bias[nh][j];
-            }
-            if (p.scale_cols != 0 && n < p.scale_cols) v *= p.scale;  // uniform test first: most GEMMs scale nothing
-            if (p.act == HK_ACT_GELU_ERF) v = (EPI == 0 || EPI == 3 || !p.out_f32) ? gelu_erf4_bf16dst(v) : gelu_erf4(v);
-            return v;
-        };
-        const int mw = m0 + wm * 128;  // first row / column of this wave's sub-tile
-        const int nw = n0 + wn * 64;
-        const int r16 = lane & 15, g4 = lane >> 4;
-        if (EPI == 0 || EPI == 3) {
-            // bf16 out, no residual: 32 rows x 128 B per round; 16-B chunk c of row r lives at chunk c ^ (r & 7)
-#pragma unroll
-            for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-                for (int i2 = 0; i2 < 2; ++i2) {
-#pragma unroll
-                    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                        for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-                            for (int j = 0; j < 2; ++j) {
-                                const f32x4 v = pre(acc[mh][nh][i2 * 2 + ii][j], nh, j, mh, i2 * 2 + ii);
-                                u32x2 o;
-                                o[0] = pack_bf16x2(v[0], v[1]);
-                                o[1] = pack_bf16x2(v[2], v[3]);
-                                const int row = ii * 16 + r16;
-                                const int ch = nh * 4 + j * 2 + (g4 >> 1);
-                                *reinterpret_cast<u32x2*>(stg + row * 128 + ((ch ^ (row & 7)) << 4) + (g4 & 1) * 8) = o;
-                            }
-#pragma unroll
-                    for (int it = 0; it < 4; ++it) {
-                        const int row = it * 8 + (lane >> 3), ch = lane & 7;
-                        const u32x4 o = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((ch ^ (row & 7)) << 4));
-                        const int m = mw + mh * 64 + i2 * 32 + row, n = nw + ch * 8;
-                        // streaming output (qkv, hid, cross K/V: hundreds of MB read once by the next kernel): non-temporal
-                        // stores measured -1.5 % step time in situ; the in-place residual stream and the attention
-                        // output, which are re-read at once, measured no gain and keep plain stores
-                        if (m < p.M && n < p.N)
-                            __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(p.C) + p.c.off(m) + n));
-                    }
-                }
-        } else {
-            // fp32 staging, 16 rows x 256 B per round; 16-B chunk c of row r lives at chunk c ^ r.  After
-            // the transpose a lane owns 4 consecutive columns of rows 4 it + g4: the residual (fp32 or bf16,
-            // possibly the output buffer itself) is read and the result stored as whole row segments, rounded
-            // once.  The residual of round k+1 is requested before the stores of round k are issued, so no
-            // round waits for a full memory round trip behind its predecessor's stores.
-            if (EPI == 2 || EPI == 4) {
-                // bf16 residual stream updated in place: a lane owns 8 consecutive columns (16 B of bf16)
-                // of rows 8 it + (lane >> 3); two staged fp32 chunks + one 16-B residual load per store.
-                // The residual rows of round r + PF are requested before round r is staged; the loads are unconditional
-                // (row clamped, N is a multiple of 256 here) so the compiler can count its waits instead of draining
-                // the queue.  HK_EPI_PF (compile time): prefetch distance in rounds.
-#ifndef HK_EPI_PF
-#define HK_EPI_PF 3
-#endif
-                constexpr int PF = HK_EPI_PF;
-                u32x4 rr[PF + 1][2];
-                auto res_load8 = [&](int rnd, u32x4(&dst)[2]) __attribute__((always_inline)) {
-#pragma unroll
-                    for (int it = 0; it < 2; ++it) {
-                        const int m = min(mw + rnd * 16 + it * 8 + (lane >> 3), p.M - 1), n = nw + (lane & 7) * 8;
-                        dst[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const __bf16*>(p.res) + p.r.off(m) + n);
-                    }
-                };
-#pragma unroll
-                for (int q = 0; q < PF; ++q) res_load8(q, rr[q]);
-#pragma unroll
-                for (int rnd = 0; rnd < 8; ++rnd) {
-                    const int mh = rnd >> 2, i = rnd & 3;
-#pragma unroll
-                    for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const int ch = nh * 8 + j * 4 + g4;
-                            *reinterpret_cast<f32x4*>(stg + r16 * 256 + ((ch ^ r16) << 4)) = pre(acc[mh][nh][i][j], nh, j, mh, i);
-                        }
-                    if (rnd + PF < 8) res_load8(rnd + PF, rr[(rnd + PF) % (PF + 1)]);
-#pragma unroll
-                    for (int it = 0; it < 2; ++it) {
-                        const int row = it * 8 + (lane >> 3), c8 = lane & 7;
-                        const f32x4 a = *reinterpret_cast<const f32x4*>(stg + row * 256 + (((2 * c8) ^ row) << 4));
-                        const f32x4 b = *reinterpret_cast<const f32x4*>(stg + row * 256 + (((2 * c8 + 1) ^ row) << 4));
-                        const int m = mw + rnd * 16 + row, n = nw + c8 * 8;
-                        const u32x4 r = rr[rnd % (PF + 1)][it];
-                        const float v0 = a[0] + bf16_lo(r[0]), v1 = a[1] + bf16_hi(r[0]), v2 = a[2] + bf16_lo(r[1]),
-                                    v3 = a[3] + bf16_hi(r[1]), v4 = b[0] + bf16_lo(r[2]), v5 = b[1] + bf16_hi(r[2]),
-                                    v6 = b[2] + bf16_lo(r[3]), v7 = b[3] + bf16_hi(r[3]);
-                        u32x4 o;
-                        o[0] = pack_bf16x2(v0, v1);
-                        o[1] = pack_bf16x2(v2, v3);
-                        o[2] = pack_bf16x2(v4, v5);
-                        o[3] = pack_bf16x2(v6, v7);
-                        if (EPI == 4) {
-                            // LayerNorm statistics of the updated residual stream, for the GEMM that consumes it with
-                            // the norm folded in: (sum, sum of squares) of this wave's 64 columns of the row -- of the
-                            // bf16 values as STORED, the ones the consumer multiplies: with the mean taken from the
-                            // unrounded sums the folded mean term would not cancel exactly against the MFMA's
-                            const float w0 = bf16_lo(o[0]), w1 = bf16_hi(o[0]), w2 = bf16_lo(o[1]), w3 = bf16_hi(o[1]),
-                                        w4 = bf16_lo(o[2]), w5 = bf16_hi(o[2]), w6 = bf16_lo(o[3]), w7 = bf16_hi(o[3]);
-                            float s1 = ((w0 + w1) + (w2 + w3)) + ((w4 + w5) + (w6 + w7));
-                            float s2 = w0 * w0;
-                            s2 = __builtin_fmaf(w1, w1, s2);
-                            s2 = __builtin_fmaf(w2, w2, s2);
-                            s2 = __builtin_fmaf(w3, w3, s2);
-                            s2 = __builtin_fmaf(w4, w4, s2);
-                            s2 = __builtin_fmaf(w5, w5, s2);
-                            s2 = __builtin_fmaf(w6, w6, s2);
-                            s2 = __builtin_fmaf(w7, w7, s2);
-                            s1 = sum8_dpp(s1);
-                            s2 = sum8_dpp(s2);
-                            if (c8 == 0 && m < p.M) {
-                                typedef __attribute__((ext_vector_type(2))) float f32x2s;
-                                *reinterpret_cast<f32x2s*>(p.row_part + ((int64_t)m * (p.N >> 6) + (nw >> 6)) * 2) = f32x2s{s1, s2};
-                            }
-                        }
-                        if (m < p.M && n < p.N)
-                            *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(p.C) + p.c.off(m) + n) = o;
-                    }
-                }
-                return;
-            }
-            f32x4 rcur[4], rnxt[4];
-            auto res_load = [&](int rnd, f32x4(&rr)[4]) {
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int m = mw + rnd * 16 + it * 4 + g4, n = nw + r16 * 4;
-                    rr[it] = (m < p.M && n < p.N) ? load_res4(p, p.r.off(m) + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            };
-            if (p.res) res_load(0, rcur);
-#pragma unroll
-            for (int rnd = 0; rnd < 8; ++rnd) {
-                const int mh = rnd >> 2, i = rnd & 3;
-#pragma unroll
-                for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int ch = nh * 8 + j * 4 + g4;
-                        *reinterpret_cast<f32x4*>(stg + r16 * 256 + ((ch ^ r16) << 4)) = pre(acc[mh][nh][i][j], nh, j, mh, i);
-                    }
-                if (p.res && rnd < 7) res_load(rnd + 1, rnxt);
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int row = it * 4 + g4, ch = r16;
-                    f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * 256 + ((ch ^ row) << 4));
-                    const int m = mw + rnd * 16 + row, n = nw + ch * 4;
-                    if (m < p.M && n < p.N) {
-                        if (p.res) v += rcur[it];
-                        if (p.out_f32) {
-                            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + p.c.off(m) + n) = v;
-                        } else {
-                            u32x2 o;
-                            o[0] = pack_bf16x2(v[0], v[1]);
-                            o[1] = pack_bf16x2(v[2], v[3]);
-                            *reinterpret_cast<u32x2*>(reinterpret_cast<__bf16*>(p.C) + p.c.off(m) + n) = o;
-                        }
-                    }
-                }
-#pragma unroll
-                for (int it = 0; it < 4; ++it) rcur[it] = rnxt[it];
-            }
-        }
-    };
+    auto epilogue = [&](int m0, int n0) __attribute__((always_inline)) { pp_epilogue<EPI>(p, acc, stg, stg, lane, wm, wn, m0, n0); };
 
     // (Measured and not kept: starting eight classes of workgroups a fraction of a tile time apart (s_sleep), so that
     // a CU's epilogue stores would meet the others' main loops instead of 255 other store bursts: every launch got slower
@@ -641,6 +655,222 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
     }
     if (wm == 0) HK_BAR();  // equalise the barrier count of the two groups
 #undef HK_MMA
+}
+
+// ---------------------------------------------------------------------------------------------
+// "Duo" kernel: TWO persistent workgroups per CU, each 4 waves (one per SIMD) on a 256x128 output tile, so that one
+// workgroup's epilogue (store-bound, matrix pipe idle: 20-30 % of the K = 1024 launches of the 256x256 kernel) runs
+// under the other workgroup's main loop.  A wave owns 128 rows x 64 columns exactly as in the 256x256 kernel (same
+// accumulator layout, same LDS fragment traffic per MFMA, the same pp_epilogue<EPI>); what changes is the operand
+// supply: a workgroup stages (256 + 128) rows per K-step instead of (256 + 256) for twice the MFMAs, i.e. 1.5x the
+// L2 -> LDS bytes per flop, issued by 4 waves instead of 8.
+//
+// K-step = 32 (one v_mfma_f32_16x16x32_bf16 deep), ring of 3 stages x {A [256][32], W [128][32]} = 72 KB, + 6 KB of
+// epilogue operands (per wave: row statistics 1 KB, bias 256 B, column sums 256 B) = 78 KB per workgroup, 156 KB per CU.
+// LDS rows are 64 B; physical 16-B chunk pc of row r holds logical chunk pc ^ g((r >> 2) & 3), g = (0, 2, 3, 1), which
+// makes every ds_read_b128 16-lane group ({0-3,12-15,20-27}, ...) hit 16 distinct 16-B slots.
+//
+// Stream of K-steps s = 0, 1, ... over the workgroup's tile list (continuous across tiles), stage s in slot s % 3.
+// Per step a wave runs
+//     H1   16 MFMA: quadrants (0,0), (0,1)   operands A-half0(s), W(s)
+//     mid  vmcnt -> own pieces of stage s+1 landed; s_barrier -> everyone's landed, and every fragment of stage s has
+//          been read (during step s-1) => slot s % 3 is free: issue the LDS-DMA of stage s+3 into it; read A-half0(s+1)
+//     H2   16 MFMA: quadrants (1,0), (1,1)   operands A-half1(s), W(s);  W-half0(s+1) is read after (1,0), W-half1(s+1)
+//          and A-half1(s+1) after (1,1)
+// so a stage is requested two full steps before its first read and every fragment is read >= 8 MFMAs ahead of its use.
+// At the last step of a tile the issue of stage s+3 and the reads of stage s+1 wait until after the epilogue: the
+// free slot's A region -- 4 KB per wave, exactly the bytes that wave's own A pieces fill -- is the wave's transpose
+// slab, so no barrier separates the epilogue from anything and its registers are free of next-step fragments.
+// ---------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void hk_gemm_duo_kernel(const GemmParams p) {
+    constexpr int BK = 32;
+    constexpr int A_EL = 256 * BK, W_EL = 128 * BK;   // elements per stage
+    constexpr int STAGE = A_EL + W_EL;                // 24 KB
+    constexpr int NS = 3;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __bf16* lds = reinterpret_cast<__bf16*>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    char* aux = smem + NS * STAGE * 2 + wave * 1536;
+
+    // ---- tile list: as in the 256x256 kernel, with 128-column tiles ----
+    const int nwg = p.nbm * p.nbn;
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int nbx = ((int)gridDim.x - xcd + 7) >> 3;
+    const int q8 = nwg >> 3, r8 = nwg & 7;
+    const int c0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int cnt = q8 + (xcd < r8 ? 1 : 0);
+    const int ntile = jb < cnt ? (cnt - jb + nbx - 1) / nbx : 0;
+    const int KT = (HK_DBG(p) & 2) ? 2 : p.K / BK;
+    if (ntile == 0) return;
+    const int S = ntile * KT;
+
+    // ---- loader: one LDS-DMA wave-instruction = 16 rows x 64 B.  Wave w fills A rows [64 w, 64 w + 64) (4 pieces: bytes
+    // [4096 w, 4096 w + 4096) of the stage) and W rows [32 w, 32 w + 32) (2 pieces).  The host guarantees plain row-major
+    // operands and whole tiles (M % 256 == 0, N % 128 == 0; leftover rows go to the multi-stage kernel), so everything that
+    // depends on the tile, the wave, the piece or k lives in the SCALAR base and a lane keeps two constant byte offsets. ----
+    // (the two offsets are recomputed from the lane id at every use -- a handful of VALU instructions per K-step -- instead
+    // of being kept live across the epilogue, where they were spilled and their reload drained the whole vmcnt queue)
+    auto lane_offsets = [&](uint32_t& voa, uint32_t& vow) __attribute__((always_inline)) {
+        int l = lane;
+        asm volatile("" : "+v"(l));   // opaque per use: not a loop invariant the compiler may hoist and spill
+        const int lrow = l >> 2;
+        const int lsw = (l & 3) ^ ((0x78 >> (((l >> 4) & 3) * 2)) & 3);   // logical chunk this lane fetches
+        voa = (uint32_t)((lrow * (int)p.a.ld + lsw * 8) * 2);
+        vow = (uint32_t)((lrow * (int)p.ldw + lsw * 8) * 2);
+    };
+    const __bf16 *sa = nullptr, *sw = nullptr;   // first element of this wave's rows of the tile being staged
+    int s_tile = 0, s_k = 0, s_slot = 0;
+    auto set_ptrs = [&]() {
+        int tm, tn;
+        tile_coords(c0 + jb + s_tile * nbx, p.nbm, p.nbn, p.gm, tm, tn);
+        sa = p.A + (int64_t)(tm * 256 + wave * 64) * p.a.ld;
+        sw = p.W + (int64_t)(tn * 128 + wave * 32) * p.ldw;
+    };
+    auto stage = [&]() -> bool {
+        if (s_tile >= ntile) return false;
+        __bf16* dst = lds + s_slot * STAGE;
+        const __bf16* ka = sa + s_k * BK;
+        const __bf16* kw = sw + s_k * BK;
+        uint32_t voa, vow;
+        lane_offsets(voa, vow);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16_s(ka + (int64_t)i * 16 * p.a.ld, voa, dst + (wave * 64 + i * 16) * BK);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16_s(kw + (int64_t)i * 16 * p.ldw, vow, dst + A_EL + (wave * 32 + i * 16) * BK);
+        s_slot = s_slot == NS - 1 ? 0 : s_slot + 1;
+        if (++s_k == KT) {
+            s_k = 0;
+            if (++s_tile < ntile) set_ptrs();
+        }
+        return true;
+    };
+    // epilogue operands of tile ti -> the wave's aux region (older than every operand load that follows them)
+    auto stage_aux = [&](int ti) {
+        if (p.bias == nullptr && EPI != 3) return;
+        int tm_, tn_;
+        tile_coords(c0 + jb + ti * nbx, p.nbm, p.nbn, p.gm, tm_, tn_);
+        if (p.bias != nullptr) glds4_s(p.bias, (uint32_t)min(tn_ * 128 + wn * 64 + lane, p.N - 1) * 4u, aux + 1024);
+        if (EPI == 3) {
+            glds4_s(p.col_c, (uint32_t)min(tn_ * 128 + wn * 64 + lane, p.N - 1) * 4u, aux + 1280);
+            glds16_v(p.row_stats + 2 * ((int64_t)tm_ * 256 + wm * 128 + 2 * lane), aux);
+        }
+    };
+
+    // ---- fragment offsets (elements): row (lane & 15), logical chunk (lane >> 4) ----
+    const int foff = (lane & 15) * BK + ((((lane >> 4)) ^ ((0x78 >> ((((lane & 15) >> 2)) * 2)) & 3)) << 3);
+    const int a_base = wm * 128 * BK;
+    const int w_base = A_EL + wn * 64 * BK;
+
+    f32x4 acc[2][2][4][2];
+    bf16x8 xa0[4], xa1[4], wf[2][2];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    zero_acc();
+    auto read_a = [&](int slot, int mh, bf16x8(&x)[4]) __attribute__((always_inline)) {
+        const __bf16* s0 = lds + slot * STAGE + a_base + mh * 64 * BK + foff;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = *reinterpret_cast<const bf16x8*>(s0 + i * 16 * BK);
+    };
+    auto read_w = [&](int slot, int nh) __attribute__((always_inline)) {
+        const __bf16* s0 = lds + slot * STAGE + w_base + foff + nh * 32 * BK;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) wf[nh][j] = *reinterpret_cast<const bf16x8*>(s0 + j * 16 * BK);
+    };
+#define HK_DUO_MMA(MH, NH, X)                                                                                           \
+    do {                                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        __builtin_amdgcn_s_setprio(1);                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[MH][NH][i][j] =  \
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[NH][j], X[i], acc[MH][NH][i][j], 0, 0, 0);                       \
+        __builtin_amdgcn_s_setprio(0);                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+    } while (0)
+
+    // ---- prologue: stages 0..2 requested, stage 0 landed, its fragments read ----
+    set_ptrs();
+    stage_aux(0);
+    stage();
+    const bool has1 = stage();
+    const bool has2 = stage();
+    if (has2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (has1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    HK_BAR();
+    read_a(0, 0, xa0);
+    read_w(0, 0);
+    read_w(0, 1);
+    read_a(0, 1, xa1);
+
+    int rslot = 0;   // slot of the step being multiplied
+    int kleft = KT;  // steps left in the current tile, this one included
+    int ti = 0;
+    // One step.  Fragment registers: A-half0, A-half1 and ONE set of W fragments, each refilled as soon as its last MFMA
+    // of the step has been issued: A-half0 at mid-step, W-half0 after quadrant (1,0), W-half1 and A-half1 after (1,1) --
+    // the next step uses them in that order (quadrants (0,0), (0,1), (1,0), (1,1)), so every fragment is read at least 8
+    // MFMAs (128 matrix cycles) before its first use.
+    for (int s = 0; s < S; ++s) {
+        const bool more = s + 1 < S;
+        const bool tile_end = kleft == 1;
+        const bool refill = more && !tile_end;
+        const int nslot = rslot == NS - 1 ? 0 : rslot + 1;
+        HK_DUO_MMA(0, 0, xa0);
+        HK_DUO_MMA(0, 1, xa0);
+        if (more) {
+            // every LDS read of this wave so far (all of stage s) has returned: stage s's slot may be refilled after the barrier
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (s + 2 < S) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            HK_BAR();
+            if (!tile_end) {
+                stage();
+                read_a(nslot, 0, xa0);
+            }
+        }
+        HK_DUO_MMA(1, 0, xa1);
+        if (refill) read_w(nslot, 0);
+        HK_DUO_MMA(1, 1, xa1);
+        if (refill) {
+            read_w(nslot, 1);
+            read_a(nslot, 1, xa1);
+        }
+        if (tile_end) {
+            int tm, tn;
+            tile_coords(c0 + jb + ti * nbx, p.nbm, p.nbn, p.gm, tm, tn);
+            // the slot just multiplied is free (no stage s+3 was issued into it): its A region, 4 KB per wave, is the
+            // wave's transpose slab -- the very bytes this wave's own A pieces will fill next
+            pp_epilogue<EPI, HK_DUO_PF>(p, acc, smem + rslot * STAGE * 2 + wave * 4096, aux, lane, wm, wn, tm * 256, tn * 128);
+            zero_acc();
+            ++ti;
+            kleft = KT + 1;
+            if (more) {
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab and aux reads done before they are refilled
+                stage_aux(ti);
+                stage();
+                read_a(nslot, 0, xa0);
+                read_w(nslot, 0);
+                read_w(nslot, 1);
+                read_a(nslot, 1, xa1);
+            }
+        }
+        --kleft;
+        rslot = nslot;
+    }
+#undef HK_DUO_MMA
 }
 
 // Multi-stage kernel for the problems too small for the persistent 256x256 kernel (Q-Former GEMMs, small
@@ -900,7 +1130,46 @@ int launch_pp(const GemmParams& p, hipStream_t stream) {
     return HK_OK;
 }
 
+std::atomic<int>& duo_mask() {
+    static std::atomic<int> m{getenv("HK_GEMM_DUO") ? (int)strtol(getenv("HK_GEMM_DUO"), nullptr, 0) : HK_GEMM_DUO_DEFAULT};
+    return m;
+}
+
+template <int EPI>
+int launch_duo(const GemmParams& p, hipStream_t stream) {
+    constexpr int LDS = 3 * (256 + 128) * 32 * 2 + 4 * 1536;  // 3 stages + epilogue operands = 78 KB: two workgroups per CU
+    static std::atomic<unsigned long long> attr_done{0};      // per device
+    {
+        const hipError_t e = hk_lds_attr_once(attr_done, reinterpret_cast<const void*>(&hk_gemm_duo_kernel<EPI>), LDS);
+        if (e != hipSuccess) {
+            hk_set_error("hk_gemm_bf16: hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e));
+            return HK_ELAUNCH;
+        }
+    }
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+            hk_set_error("hk_gemm_bf16: device setup (duo)");
+            return HK_ELAUNCH;
+        }
+        ncu = n;
+    }
+    GemmParams q = p;
+    q.nbm = (p.M + 255) / 256;
+    q.nbn = (p.N + 127) / 128;
+    const int ntiles = q.nbm * q.nbn;
+    const int grid = ntiles < 2 * ncu ? ntiles : 2 * ncu;
+    hipLaunchKernelGGL(hk_gemm_duo_kernel<EPI>, dim3(grid), dim3(256), LDS, stream, q);
+    HK_CHECK_LAUNCH("hk_gemm_bf16");
+    return HK_OK;
+}
+
 }  // namespace
+
+extern "C" int hk_gemm_duo_mask(int mask) {
+    return mask < 0 ? duo_mask().load(std::memory_order_relaxed) : duo_mask().exchange(mask & 31, std::memory_order_relaxed);
+}
 
 extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
     HK_REQUIRE(d != nullptr, "hk_gemm_bf16: null descriptor");
@@ -1076,11 +1345,25 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
                 p.M = tail.m_off;
             }
         }
+        // HK_GEMM_DUO: bit e set = epilogue kind e runs on the two-workgroups-per-CU 256x128 kernel (hk_gemm_duo_kernel)
+        // instead of the 256x256 one (A/B switch; the default is what measured faster per epilogue kind)
+        const int duo = duo_mask().load(std::memory_order_relaxed);
+        const int epi = p.row_stats ? 3 : (!p.out_f32 && !p.res) ? 0 : (!p.out_f32 && p.res_bf16) ? (p.row_part ? 4 : 2) : 1;
+        const bool use_duo = ((duo >> epi) & 1) != 0 && p.K >= 128 && d->N % 128 == 0 && d->a_rows.rows_per_batch == 0 &&
+                             p.M >= 256;
+        if (use_duo && p.M % 256 != 0) {
+            // the duo kernel addresses whole 256-row tiles through scalar bases: leftover rows join (or become) the tail launch
+            const int whole = p.M / 256 * 256;
+            tail.m_off = whole;
+            tail.M = d->M - whole;
+            p.M = whole;
+        }
         int rc;
-        if (p.row_stats) rc = launch_pp<3>(p, s);
-        else if (!p.out_f32 && !p.res) rc = launch_pp<0>(p, s);
-        else if (!p.out_f32 && p.res_bf16) rc = p.row_part ? launch_pp<4>(p, s) : launch_pp<2>(p, s);
-        else rc = launch_pp<1>(p, s);
+        if (epi == 3) rc = use_duo ? launch_duo<3>(p, s) : launch_pp<3>(p, s);
+        else if (epi == 0) rc = use_duo ? launch_duo<0>(p, s) : launch_pp<0>(p, s);
+        else if (epi == 4) rc = use_duo ? launch_duo<4>(p, s) : launch_pp<4>(p, s);
+        else if (epi == 2) rc = use_duo ? launch_duo<2>(p, s) : launch_pp<2>(p, s);
+        else rc = use_duo ? launch_duo<1>(p, s) : launch_pp<1>(p, s);
         if (rc != HK_OK || tail.M == 0) return rc;
         return small(tail);
     }

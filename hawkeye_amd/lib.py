@@ -119,6 +119,7 @@ SYMBOLS = {
     "hk_qformer_embed_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                        C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "hk_mfma_probe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "hk_gemm_duo_mask": (C.c_int, [C.c_int]),
     "hk_version": (C.c_int, []),
     "hk_arch": (C.c_char_p, []),
     "hk_last_error": (C.c_size_t, [C.c_char_p, C.c_size_t]),

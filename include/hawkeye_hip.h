@@ -326,6 +326,13 @@ int hk_qformer_embed_bwd(const float* dz, const int64_t* input_ids, float* dquer
  * one launch = grid * iters * 524288 flops.  out: fp32 [grid * 256]. */
 int hk_mfma_probe(const void* seed_bf16_2048, float* out, int32_t grid, int32_t iters, int32_t kind, void* stream);
 
+/* Tuning switch, no reference counterpart: which epilogue kinds of hk_gemm_bf16's large-problem path run on the
+ * two-workgroups-per-CU 256x128 kernel (one workgroup's store-bound epilogue under the other's main loop) instead of
+ * the one-workgroup 256x256 kernel.  Bit e of `mask` = epilogue kind e (0 bf16 out, 1 fp32 out / fp32 residual, 2 bf16
+ * residual stream in place, 3 folded LayerNorm, 4 = 2 + row_part).  mask < 0 only queries.  Returns the mask in force
+ * before the call.  Process-wide; the environment variable HK_GEMM_DUO (read once) sets the initial value. */
+int hk_gemm_duo_mask(int mask);
+
 /* Library identification and last-error text. */
 int hk_version(void);
 const char* hk_arch(void);

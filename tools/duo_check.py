@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""The two-workgroups-per-CU GEMM (hk_gemm_duo_kernel) against the 256x256 kernel: same bits expected (same MFMA order
+per output element), then interleaved timings at the ViT shapes.  usage: tools/duo_check.py [check] [time] [M]"""
+import os
+import sys
+
+import torch
+
+torch.set_grad_enabled(False)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hawkeye_amd import lib as L, ops  # noqa: E402
+
+DEV = "cuda:0"
+lib = L.load()
+
+
+def run(kind, x, w, b, res, st, cc, rp, out):
+    if kind == 3:
+        return ops.linear(x, w, b, act="gelu" if out.shape[1] == 4096 else "none", out=out, row_stats=st, col_c=cc)
+    if kind == 0:
+        return ops.linear(x, w, b, act="gelu" if out.shape[1] == 4096 else "none", out=out)
+    if kind == 1:
+        return ops.linear(x, w, b, residual=res, out_dtype=torch.float32, out=out)
+    if kind == 2:
+        return ops.linear(x, w, b, residual=out, out_dtype=torch.bfloat16, out=out)
+    if kind == 4:
+        return ops.linear(x, w, b, residual=out, out_dtype=torch.bfloat16, out=out, row_part=rp)
+
+
+def make(M, N, K, kind):
+    g = torch.Generator(device=DEV).manual_seed(M + N + K + kind)
+    x = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=DEV, generator=g) * 0.03).to(torch.bfloat16)
+    b = torch.randn(N, device=DEV, generator=g)
+    res = torch.randn(M, N, device=DEV, generator=g) if kind == 1 else None
+    st = cc = rp = None
+    if kind == 3:
+        st = torch.zeros((M + 255) // 256 * 256, 2, device=DEV)
+        ops.row_stats(x, 1e-6, out=st[:M])
+        cc = w.float().sum(1).contiguous()
+        st = st[:M]
+    if kind == 4:
+        rp = torch.zeros(M, N // 64, 2, device=DEV)
+    odt = torch.float32 if kind == 1 else torch.bfloat16
+    out0 = torch.randn(M, N, device=DEV, generator=g).to(odt)
+    return x, w, b, res, st, cc, rp, out0
+
+
+def check():
+    ok = True
+    for kind in (0, 3, 2, 4, 1):
+        for (M, N, K) in ((25088, 1024 if kind in (2, 4) else 3072, 1024), (25088 + 77, 1024, 4096 if kind != 3 else 1024),
+                          (16384, 4096 if kind in (0, 3) else 1024, 1024), (32768 + 256, 1024, 768)):
+            args = make(M, N, K, kind)
+            outs = []
+            for mask in (0, 31):
+                lib.hk_gemm_duo_mask(mask)
+                out = args[-1].clone()
+                rp = args[6].clone() if args[6] is not None else None
+                run(kind, *args[:6], rp, out)
+                torch.cuda.synchronize()
+                outs.append((out, rp))
+            same = torch.equal(outs[0][0], outs[1][0])
+            rps = True if outs[0][1] is None else torch.equal(outs[0][1], outs[1][1])
+            d = (outs[0][0].float() - outs[1][0].float()).abs().max().item()
+            print(f"epi {kind} M={M} N={N} K={K}: identical={same} row_part identical={rps} max|diff|={d:.3e}", flush=True)
+            ok = ok and same and rps
+    lib.hk_gemm_duo_mask(0)
+    print("CHECK", "OK" if ok else "FAILED", flush=True)
+    return ok
+
+
+def timeit(fn, iters=8, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+def time_all(M=100352):
+    shapes = (("qkv (fold)", 3, 3072, 1024), ("fc1+gelu (fold)", 3, 4096, 1024), ("proj (row_part)", 4, 1024, 1024),
+              ("fc2 (row_part)", 4, 1024, 4096), ("ckv", 0, 9216, 1024), ("patch", 2, 1024, 768))
+    for name, kind, N, K in shapes:
+        args = make(M, N, K, kind)
+        out = args[-1]
+        res = {0: [], 31: []}
+        for rnd in range(3):
+            for mask in (0, 31):
+                lib.hk_gemm_duo_mask(mask)
+                res[mask].append(timeit(lambda: run(kind, *args[:7], out)))
+        fl = 2.0 * M * N * K
+        a, b = min(res[0]), min(res[31])
+        print(f"{name:18s} M={M} N={N} K={K}: 256x256 {a:8.1f} us ({fl/a/1e6:7.1f} TF)   duo {b:8.1f} us ({fl/b/1e6:7.1f} TF)   "
+              f"ratio {b/a:.3f}   all: {[round(v) for v in res[0]]} vs {[round(v) for v in res[31]]}", flush=True)
+        del args, out
+    lib.hk_gemm_duo_mask(0)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["check", "time"]
+    if "check" in what:
+        if not check():
+            sys.exit(1)
+    if "time" in what:
+        time_all()
