@@ -13,6 +13,7 @@ alpha=32 on q_proj / v_proj) are merged into the dense weights at load: W + (alp
 There is no CPU path: everything below enqueues C-ABI calls of libhawkeye_hip.so (include/hawkeye_hip.h).
 """
 import ctypes as C
+from collections import OrderedDict
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -20,6 +21,7 @@ import torch
 from . import lib as L
 from . import ops
 from .config import LlmConfig
+from .engine import _Pool
 
 LOG2E = 1.4426950408889634
 _PREFIXES = ("llama_model.base_model.model.", "llama_model.", "base_model.model.", "")
@@ -50,11 +52,15 @@ def strip_prefix(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     raise RuntimeError("no LlamaForCausalLM weights (model.embed_tokens.weight) found in the state dict")
 
 
+MAX_PLANS = 64      # host-side descriptor sets kept (LRU); device memory is pooled, not per plan
+
+
 class _Plan:
     def __init__(self):
         self.ws: Dict[str, torch.Tensor] = {}
         self.steps: List[Tuple] = []
         self.keep: List = []
+        self.pool_epoch = 0
 
 
 class LlamaPrefill:
@@ -71,7 +77,33 @@ class LlamaPrefill:
             raise RuntimeError("hidden_size must be a multiple of 256 and intermediate_size of 64")
         self.lib = L.load()
         self.w: Dict[str, torch.Tensor] = {}
-        self.plans: Dict[Tuple[int, int, bool, bool], _Plan] = {}   # (B, S, masked, explicit position ids)
+        # Prompt length differs per example, so an eval run meets a new (B, S) on almost every call.  Workspace tensors
+        # are views of ONE pool of grow-only buffers (the engine's _Pool): the memory held is the largest size each
+        # buffer was ever asked for (qkv alone is 2.2 GB at B = 8, S = 352), not the sum over shapes; plans are host-side
+        # descriptor sets, kept LRU and rebuilt when a buffer had to grow.
+        self.pool = _Pool(self.device)
+        self.plans: "OrderedDict[Tuple[int, int, bool, bool], _Plan]" = OrderedDict()   # (B, S, masked, explicit position ids)
+
+    def pooled_bytes(self) -> int:
+        return self.pool.nbytes()
+
+    def plan_for(self, B: int, S: int, masked: bool, with_pos: bool) -> "_Plan":
+        key = (B, S, masked, with_pos)
+        plan = self.plans.get(key)
+        if plan is not None and plan.pool_epoch == self.pool.epoch:
+            self.plans.move_to_end(key)
+            return plan
+        if plan is not None:
+            del self.plans[key]
+        epoch = self.pool.epoch
+        plan = self._build_plan(B, S, masked, with_pos)
+        if self.pool.epoch != epoch:
+            self.plans.clear()              # a buffer grew: every older plan points into the released allocation
+        plan.pool_epoch = self.pool.epoch
+        self.plans[key] = plan
+        while len(self.plans) > MAX_PLANS:
+            self.plans.popitem(last=False)
+        return plan
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, sd: Dict[str, torch.Tensor], lora_alpha: float = 32.0):
@@ -147,20 +179,21 @@ class LlamaPrefill:
         bf16, f32 = torch.bfloat16, torch.float32
         with torch.cuda.device(dev):
             ws = plan.ws
-            ws["src"] = torch.empty((M,), dtype=torch.int64, device=dev)
-            ws["mask"] = torch.empty((B, S), dtype=torch.int64, device=dev)
-            ws["kbias"] = torch.empty((B, S), dtype=f32, device=dev)
-            ws["x"] = torch.empty((M, D), dtype=f32, device=dev)           # residual stream
-            ws["xn"] = torch.empty((M, D), dtype=bf16, device=dev)
-            ws["qkv"] = torch.empty((Lyr, M, 3 * D), dtype=bf16, device=dev)  # per layer: q | k | v; k, v = the KV cache
-            ws["att"] = torch.empty((M, D), dtype=bf16, device=dev)
-            ws["gu"] = torch.empty((M, 2 * I), dtype=bf16, device=dev)
-            ws["act"] = torch.empty((M, I), dtype=bf16, device=dev)
-            ws["last"] = torch.empty((B,), dtype=torch.int64, device=dev)
-            ws["pos"] = torch.empty((M,), dtype=torch.int32, device=dev) if with_pos else None
-            ws["hl_f"] = torch.empty((B, D), dtype=f32, device=dev)
-            ws["hl_b"] = torch.empty((B, D), dtype=bf16, device=dev)
-            ws["logits"] = torch.empty((B, V), dtype=f32, device=dev)
+            buf = self.pool.view
+            ws["src"] = buf("src", (M,), torch.int64)
+            ws["mask"] = buf("mask", (B, S), torch.int64)
+            ws["kbias"] = buf("kbias", (B, S), f32)
+            ws["x"] = buf("x", (M, D), f32)           # residual stream
+            ws["xn"] = buf("xn", (M, D), bf16)
+            ws["qkv"] = buf("qkv", (Lyr, M, 3 * D), bf16)  # per layer: q | k | v; k, v = the KV cache
+            ws["att"] = buf("att", (M, D), bf16)
+            ws["gu"] = buf("gu", (M, 2 * I), bf16)
+            ws["act"] = buf("act", (M, I), bf16)
+            ws["last"] = buf("last", (B,), torch.int64)
+            ws["pos"] = buf("pos", (M,), torch.int32) if with_pos else None
+            ws["hl_f"] = buf("hl_f", (B, D), f32)
+            ws["hl_b"] = buf("hl_b", (B, D), bf16)
+            ws["logits"] = buf("logits", (B, V), f32)
         P = lambda t: t.data_ptr()  # noqa: E731
         x, xn, att, gu, act = ws["x"], ws["xn"], ws["att"], ws["gu"], ws["act"]
         qscale = (hd ** -0.5) * LOG2E
@@ -207,7 +240,8 @@ class LlamaPrefill:
         default ids is refused: the reference never runs that combination and its positions would be shifted.
         Returns {"hidden": bf16 [B,S,D] after the final RMSNorm,
         "logits": fp32 [B,V] at each row's last valid position, "kv": [(k, v)] per layer as [B,S,H,hd] bf16 views
-        (k post-rotary), valid until the next call with the same (B, S)}.  Padded positions hold unspecified values."""
+        (k post-rotary)}.  Every returned tensor is a view of the pooled workspace, valid until the NEXT prefill call of this
+        object (whatever its shape): clone what generation keeps.  Padded positions hold unspecified values."""
         cfg = self.cfg
         if not self.w:
             raise RuntimeError("LlamaPrefill: load_state_dict() has not been called")
@@ -226,11 +260,7 @@ class LlamaPrefill:
                 raise RuntimeError('position_ids must be None, "generate" (needs attention_mask) or an int tensor [B,S]')
         elif with_pos and (tuple(position_ids.shape) != (B, S) or position_ids.device != self.device):
             raise RuntimeError(f"position_ids must be an integer tensor [{B},{S}] on {self.device}")
-        key = (B, S, masked, with_pos)
-        plan = self.plans.get(key)
-        if plan is None:
-            plan = self._build_plan(B, S, masked, with_pos)
-            self.plans[key] = plan
+        plan = self.plan_for(B, S, masked, with_pos)
         ws = plan.ws
         D, H, hd = cfg.hidden_size, cfg.num_attention_heads, cfg.head_dim
         with torch.cuda.device(self.device):

@@ -61,7 +61,10 @@ def check():
                 torch.cuda.synchronize()
                 outs.append((out, rp))
             same = torch.equal(outs[0][0], outs[1][0])
-            rps = True if outs[0][1] is None else torch.equal(outs[0][1], outs[1][1])
+            # rows past the last whole 256-row tile go to the multi-stage kernel on the duo path: its row sums are added in
+            # another order (fp32 rounding), everything else must be the same bits
+            rps = True if outs[0][1] is None else (torch.equal(outs[0][1], outs[1][1]) if M % 256 == 0 else
+                                                   torch.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-4))
             d = (outs[0][0].float() - outs[1][0].float()).abs().max().item()
             print(f"epi {kind} M={M} N={N} K={K}: identical={same} row_part identical={rps} max|diff|={d:.3e}", flush=True)
             ok = ok and same and rps
