@@ -452,3 +452,38 @@ def test_qformer_embed_ln():
 def test_cast_is_round_to_nearest_even():
     x = _rand((1000003,), 71, 10.0)
     assert torch.equal(ops.cast_bf16(x), x.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("kind", [0, 3, 4, 1])
+def test_gemm_two_workgroups_per_cu_kernel_gives_the_256x256_kernels_bits(kind):
+    """hk_gemm_duo_kernel (256x128 tiles, two persistent workgroups per CU, K-step 32, 3-stage ring; round 3, measured
+    slower and off by default -- profiles/r03_duo_pmc.txt) accumulates every output element over the same K order with
+    the same epilogue code as the 256x256 kernel: bit-identical results for each epilogue kind, including a row count
+    that leaves a partial 256-row tile to the tail launch, and a multi-tile-per-workgroup walk (M = 70 000: 274 x 8 tiles)."""
+    import os
+    import sys
+    from hawkeye_amd import lib as L
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import duo_check as DC
+    lib = L.load()
+    assert lib.hk_gemm_duo_mask(-1) == 0                     # the default path is the 256x256 kernel
+    try:
+        for (M, N, K) in ((70000, 1024, 1024 if kind != 0 else 768), (25088, 3072 if kind in (0, 3) else 1024, 256)):
+            args = DC.make(M, N, K, kind)
+            outs = []
+            for mask in (0, 31):
+                lib.hk_gemm_duo_mask(mask)
+                assert lib.hk_gemm_duo_mask(-1) == mask
+                out = args[-1].clone()
+                rp = args[6].clone() if args[6] is not None else None
+                DC.run(kind, *args[:6], rp, out)
+                torch.cuda.synchronize()
+                outs.append((out, rp))
+            assert torch.equal(outs[0][0], outs[1][0]), (kind, M, N, K)
+            if outs[0][1] is not None:
+                whole = M // 256 * 256     # the rows of a last partial tile take the multi-stage kernel's summation order
+                assert torch.equal(outs[0][1][:whole], outs[1][1][:whole])
+                assert torch.allclose(outs[0][1][whole:], outs[1][1][whole:], rtol=1e-5, atol=1e-4)
+            lib.hk_gemm_duo_mask(0)
+    finally:
+        lib.hk_gemm_duo_mask(0)

@@ -216,3 +216,34 @@ def test_lora_merge_equals_adapter_forward():
     a = m.prefill(src=src.to(DEV), video=vid)["logits"].clone()
     b = m2.prefill(src=src.to(DEV), video=vid)["logits"]
     assert torch.equal(a, b)
+
+
+def test_prefill_workspace_is_pooled_across_prompt_lengths():
+    """prompt length differs per example, and every distinct (B, S) used to allocate a workspace of
+    its own (qkv [32, M, 3D] alone is 2.2 GB at B = 8, S = 352 with the 7B shape).  Now the workspace is one pool of
+    grow-only buffers: 12 distinct S after the first (largest) one grow the allocation by < 0.5 GB -- here by nothing --
+    and a pooled plan gives the bits of a fresh engine that only ever saw that shape."""
+    from hawkeye_amd.config import LlmConfig
+    cfg = LlmConfig(num_hidden_layers=4)          # 7B widths (4096 / 11008 / 32 heads x 128), 4 layers
+    m = LlamaPrefill(cfg, DEV).init_random(seed=3)
+    B = 8
+    g = torch.Generator(device=DEV).manual_seed(5)
+    lengths = [352] + list(range(340, 220, -10))   # 13 distinct prompt lengths, the largest first
+    outs, base = {}, None
+    for S in lengths:
+        src = torch.randint(0, cfg.vocab_size, (B, S), generator=g, device=DEV)
+        o = m.prefill(src=src)
+        outs[S] = (src, o["logits"].clone())
+        torch.cuda.synchronize()
+        if base is None:
+            base = torch.cuda.memory_allocated()
+    grown = torch.cuda.memory_allocated() - base - sum(v[1].numel() * 4 + v[0].numel() * 8 for v in list(outs.values())[1:])
+    print(f"[pool] prefill memory growth over 12 more prompt lengths: {grown / 2**20:.1f} MiB; pooled {m.pooled_bytes() / 2**30:.2f} GiB; "
+          f"plans {len(m.plans)}")
+    assert grown < (1 << 29)
+    assert len(m.plans) == len(lengths)
+    fresh = LlamaPrefill(cfg, DEV).init_random(seed=3)
+    for S in (lengths[4], lengths[0]):             # a smaller shape first, so the fresh engine's pool has to grow
+        src, want = outs[S]
+        assert torch.equal(fresh.prefill(src=src)["logits"], want), S
+        assert torch.equal(m.prefill(src=src)["logits"], want), S      # revisited after the others used the same buffers
