@@ -112,6 +112,8 @@ SYMBOLS = {
     "hk_colsum_static": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "hk_transpose_bf16": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(HkRows), C.c_int64, C.c_int32, C.c_void_p,
                                     C.c_int64, C.c_void_p]),
+    "hk_wgrad_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(HkRows), C.c_void_p, C.c_int64, C.c_void_p,
+                                C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "hk_gelu_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "hk_gelu_bwd_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "hk_qformer_embed_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,

@@ -18,6 +18,7 @@ Memory design (sized for 288 GB, not for reuse):
     masks are never stored: the backward regenerates them from (seed, site, index).
 """
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -327,11 +328,15 @@ class QFormerTrainEngine:
             dcq = plan.buf("dcq", (Rq, d), bf16, dev)
             dkvc = plan.buf("dkvc", (M, KVW), bf16, dev)
             dsum = plan.buf("dsum", (B, H, max(S, nq)), f32, dev)
-            rmax = pad64(max(R, M))
-            tA = plan.buf("tA", (max(3 * d, I, LH, KVW) * rmax,), bf16, dev)
-            tB = plan.buf("tB", (max(d, I, D) * rmax,), bf16, dev)
+            # HK_WGRAD_FUSED=0 (A/B aid): round 2's weight gradients -- transposed copies of dY and X, the inference GEMM on
+            # them and a column-sum launch for the bias -- instead of the one-launch hk_wgrad_bf16
+            fused_wgrad = os.environ.get("HK_WGRAD_FUSED", "1") != "0" and all(v % 128 == 0 for v in (d, I, LH, KVW, D))
+            if not fused_wgrad:
+                rmax = pad64(max(R, M))
+                tA = plan.buf("tA", (max(3 * d, I, LH, KVW) * rmax,), bf16, dev)
+                tB = plan.buf("tB", (max(d, I, D) * rmax,), bf16, dev)
+                csws = plan.buf("csws", (L.HK_COLSUM_MAX_SPLIT * max(3 * d, I, LH, KVW),), f32, dev)
             lnws = plan.buf("lnws", (L.HK_LNBWD_MAX_BLOCKS * 2 * d,), f32, dev)
-            csws = plan.buf("csws", (L.HK_COLSUM_MAX_SPLIT * max(3 * d, I, LH, KVW),), f32, dev)
 
         def lname(i, s):
             return f"{q}encoder.layer.{i}.{s}"
@@ -426,7 +431,11 @@ class QFormerTrainEngine:
                        "hk_transpose_bf16"))
 
         def wgrad(dy_ptr, rows, n_out, x_ptr, x_rows, k_in, wname, bname):
-            """dW[n_out, k_in] = dY^T X (contraction over `rows`, zero padded to 64), db = column sums of dY."""
+            """dW[n_out, k_in] = dY^T X (contraction over `rows`), db = column sums of dY."""
+            if fused_wgrad:
+                Bw.append((lib.hk_wgrad_bf16, (dy_ptr, n_out, x_ptr, self._rows(plan, x_rows), ar.g32(wname), k_in, ar.g32(bname),
+                                               rows, n_out, k_in), "hk_wgrad_bf16"))
+                return
             transpose(dy_ptr, None, rows, n_out, P(tA))
             transpose(x_ptr, x_rows, rows, k_in, P(tB))
             rp = pad64(rows)

@@ -156,6 +156,24 @@ def transpose(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def wgrad(dy: torch.Tensor, x: torch.Tensor, x_rows: Optional[Rows] = None, rows: Optional[int] = None,
+          bias: bool = True) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """dW [N, K] fp32 = dy^T x and db [N] = column sums of dy, in one launch (hk_wgrad_bf16).  dy bf16 [R, N] (last dim
+    dense); x bf16: [R, K], or any buffer addressed through x_rows = (ld, rows_per_batch, batch_stride) with `rows` given."""
+    _need(dy, torch.bfloat16, "dy")
+    _need(x, torch.bfloat16, "x")
+    R, N = (dy.shape[0] if rows is None else rows), dy.shape[1]
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise RuntimeError("wgrad: x must be a 2-D tensor with a dense last dimension (K)")
+    K = x.shape[1]
+    xr = L.HkRows(x.stride(0), 0, 0) if x_rows is None else L.HkRows(*x_rows)
+    dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+    db = torch.empty((N,), dtype=torch.float32, device=dy.device) if bias else None
+    L.check(L.load().hk_wgrad_bf16(dy.data_ptr(), dy.stride(0), x.data_ptr(), C.byref(xr), dw.data_ptr(), K,
+                                   None if db is None else db.data_ptr(), R, N, K, _stream()), "hk_wgrad_bf16")
+    return dw, db
+
+
 def gelu(u: torch.Tensor) -> torch.Tensor:
     _need(u, torch.bfloat16, "u")
     g = torch.empty_like(u)

@@ -307,6 +307,16 @@ int hk_colsum_static(const void* x, int32_t dtype, int64_t ld, int64_t R, int32_
 int hk_transpose_bf16(const void* x, int32_t in_dtype, const hk_rows* x_rows, int64_t R, int32_t C, void* out,
                       int64_t ldo, void* stream);
 
+/* Weight gradient of a Linear in one launch (what autograd computes for nn.Linear under tasks/train_it.py:63-80):
+ *   dw[n][k] = sum_r dy[r][n] * x[r][k]   (fp32, row stride lddw, overwritten)
+ *   db[n]    = sum_r dy[r][n]             (fp32, when db != NULL)
+ * dy bf16 [R, N] plain rows of stride ldy; x bf16 [R, K] with rows mapped by x_rows (NULL = plain [R, K]).  The
+ * contraction runs over the ROW index of both operands: tiles are staged row-major and read with gfx950's transposing
+ * LDS read, so no transposed copy of either operand is made (it replaces hk_transpose_bf16 x 2 + hk_gemm_bf16 +
+ * hk_colsum of round 2).  Any R >= 1; N and K multiples of 128.  Summation order is fixed: bit-reproducible. */
+int hk_wgrad_bf16(const void* dy, int64_t ldy, const void* x, const hk_rows* x_rows, float* dw, int64_t lddw, float* db,
+                  int64_t R, int32_t N, int32_t K, void* stream);
+
 /* exact-erf GELU on bf16 and its backward du = dg * gelu'(u) (BertIntermediate, Qformer.py:387-390); n % 8 == 0. */
 int hk_gelu_bf16(const void* u, void* g, int64_t n, void* stream);
 int hk_gelu_bwd_bf16(const void* dg, const void* u, void* du, int64_t n, void* stream);

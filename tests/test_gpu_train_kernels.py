@@ -203,3 +203,63 @@ def test_embedding_gather_and_backward():
     ref.backward(dz)
     dq, dw, dp = T.embed_bwd(dz, ids, nq, V, P)
     assert _rel(dq, qq.grad) < 1e-6 and _rel(dw, ww.grad) < 1e-6 and _rel(dp, pp.grad) < 1e-6
+
+
+def test_wgrad_exact_on_integer_data_catches_any_transposition():
+    """hk_wgrad_bf16 on small integers (exact in bf16 and in the fp32 accumulator): dW = dY^T X and db = column sums
+    must come out EXACT.  dY and X are asymmetric and R is not a multiple of 32, so a swapped output index, a permuted
+    contraction order between the two transposed fragment reads, or an unmasked tail row shows as a wrong integer."""
+    R, N, K = 75, 256, 384
+    g = torch.Generator(device="cpu").manual_seed(5)
+    dy = torch.randint(-3, 4, (R, N), generator=g).float()
+    x = torch.randint(-4, 5, (R, K), generator=g).float()
+    x[:, 0] = torch.arange(R) % 7          # structure along the contraction index
+    dy[:, 1] = (torch.arange(R) % 5) - 2
+    dw, db = T.wgrad(dy.to(DEV, torch.bfloat16), x.to(DEV, torch.bfloat16))
+    assert torch.equal(dw.cpu(), dy.t() @ x)
+    assert torch.equal(db.cpu(), dy.sum(0))
+    # the rows past R inside the last 32-row step are never read as data: poison the memory behind the operands
+    big_y = torch.full((R + 40, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    big_x = torch.full((R + 40, K), float("nan"), dtype=torch.bfloat16, device=DEV)
+    big_y[:R], big_x[:R] = dy.to(DEV, torch.bfloat16), x.to(DEV, torch.bfloat16)
+    dw2, db2 = T.wgrad(big_y[:R], big_x[:R])
+    assert torch.equal(dw2, dw) and torch.equal(db2, db)
+
+
+@pytest.mark.parametrize("R,N,K", [(256, 768, 768), (192, 3072, 768), (64, 768, 3072), (4704, 1536, 1024), (1, 128, 128), (33, 128, 256)])
+def test_wgrad_matches_fp32_autograd_shapes_of_the_stage3_step(R, N, K):
+    """The Q-Former's dense layers at B = 2 (R = 256 / 192 / 64 rows) and a slice of the fused cross K/V projection
+    (R = B N = 4704): against fp32 matmul on the same bf16-rounded operands; bit-identical on a repeat call."""
+    dy, x = _rand((R, N), 21, 0.5, torch.bfloat16), _rand((R, K), 22, 1.0, torch.bfloat16)
+    dw, db = T.wgrad(dy, x)
+    ref_w, ref_b = dy.float().t() @ x.float(), dy.float().sum(0)
+    assert _rel(dw, ref_w) < 2e-5 and _rel(db, ref_b) < 2e-5
+    dw2, db2 = T.wgrad(dy, x)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    dw3, none = T.wgrad(dy, x, bias=False)
+    assert none is None and torch.equal(dw3, dw)
+
+
+def test_wgrad_reads_x_through_a_row_map():
+    """x = the query rows [:, :96] of a [B, S, d] hidden state (rows_per_batch = 96, batch_stride = S d), as the
+    backward addresses them in place (no slice copy)."""
+    B, S, nq, d, N = 3, 128, 96, 256, 384
+    h = _rand((B, S, d), 31, 1.0, torch.bfloat16)
+    dy = _rand((B * nq, N), 32, 0.5, torch.bfloat16)
+    dw, db = T.wgrad(dy, h.view(B * S, d), x_rows=(d, nq, S * d), rows=B * nq)
+    ref = dy.float().t() @ h[:, :nq].reshape(B * nq, d).float()
+    assert _rel(dw, ref) < 2e-5
+    # text rows: offset base pointer + the same map
+    Lt = S - nq
+    dyt = _rand((B * Lt, N), 33, 0.5, torch.bfloat16)
+    xt = h.view(-1)[nq * d:]
+    dwt, _ = T.wgrad(dyt, xt.view(B * S - nq, d), x_rows=(d, Lt, S * d), rows=B * Lt)
+    assert _rel(dwt, dyt.float().t() @ h[:, nq:].reshape(B * Lt, d).float()) < 2e-5
+
+
+def test_wgrad_rejects_bad_shapes():
+    from hawkeye_amd import lib as L
+    dy, x = _rand((64, 100), 1, 1.0, torch.bfloat16), _rand((64, 128), 2, 1.0, torch.bfloat16)
+    with pytest.raises(RuntimeError, match="multiples of 128"):
+        T.wgrad(dy, x)
+    assert L.load().hk_wgrad_bf16(None, 0, None, None, None, 0, None, 0, 0, 0, None) == 1
