@@ -47,6 +47,11 @@ class HkAttnDesc(C.Structure):
     ]
 
 
+class HkTransposeJob(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("ld", C.c_int64), ("ldo", C.c_int64),
+                ("R", C.c_int32), ("C", C.c_int32), ("tile0", C.c_int32), ("pad_", C.c_int32)]
+
+
 class HkDropout(C.Structure):
     _fields_ = [("p", C.c_float), ("p_path", C.c_float), ("seed", C.c_uint32), ("site", C.c_uint32),
                 ("path_site", C.c_uint32), ("rows_per_sample", C.c_int32)]
@@ -112,6 +117,7 @@ SYMBOLS = {
     "hk_colsum_static": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "hk_transpose_bf16": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(HkRows), C.c_int64, C.c_int32, C.c_void_p,
                                     C.c_int64, C.c_void_p]),
+    "hk_transpose_f32_bf16_batch": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "hk_wgrad_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(HkRows), C.c_void_p, C.c_int64, C.c_void_p,
                                 C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "hk_gelu_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

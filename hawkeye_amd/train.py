@@ -216,6 +216,9 @@ class QFormerTrainEngine:
         """Per optimizer step: one cast of the whole arena to bf16, one transpose per Linear (W^T for dgrad)."""
         ar, dev = self.arena, self.device
         steps = [(self.lib.hk_cast_f32_bf16, (ar.flat.data_ptr(), ar.bf16.data_ptr(), ar.total), "hk_cast_f32_bf16")]
+        # HK_PACK_BATCH=0 (A/B aid): one hk_transpose_bf16 launch per weight, as in round 2
+        batch = os.environ.get("HK_PACK_BATCH", "1") != "0"
+        jobs, tile0 = [], 0
         with torch.cuda.device(dev):
             for key, wnames, k_in in self._lin_names():
                 n_out = sum(ar.params[ar.names.index(n)].shape[0] for n in wnames)
@@ -226,9 +229,20 @@ class QFormerTrainEngine:
                 col = 0
                 for n in wnames:
                     rows = ar.params[ar.names.index(n)].shape[0]
-                    steps.append((self.lib.hk_transpose_bf16,
-                                  (ar.p32(n), L.HK_DT_F32, None, rows, k_in, t.data_ptr() + 2 * col, n_out), "hk_transpose_bf16"))
+                    if batch:
+                        jobs.append(L.HkTransposeJob(ar.p32(n), t.data_ptr() + 2 * col, k_in, n_out, rows, k_in, tile0, 0))
+                        tile0 += -(-rows // 64) * -(-k_in // 64)
+                    else:
+                        steps.append((self.lib.hk_transpose_bf16,
+                                      (ar.p32(n), L.HK_DT_F32, None, rows, k_in, t.data_ptr() + 2 * col, n_out), "hk_transpose_bf16"))
                     col += rows
+            if batch:
+                # the job table lives on the device (filled once: the arena and the W^T buffers never move)
+                raw = (L.HkTransposeJob * len(jobs))(*jobs)
+                host = torch.frombuffer(bytearray(bytes(raw)), dtype=torch.uint8)
+                self._pack_jobs = host.to(dev)
+                steps.append((self.lib.hk_transpose_f32_bf16_batch, (self._pack_jobs.data_ptr(), len(jobs), tile0),
+                              "hk_transpose_f32_bf16_batch"))
         self._pack_steps = steps
 
     def pack(self, force: bool = False):

@@ -307,6 +307,18 @@ int hk_colsum_static(const void* x, int32_t dtype, int64_t ld, int64_t R, int32_
 int hk_transpose_bf16(const void* x, int32_t in_dtype, const hk_rows* x_rows, int64_t R, int32_t C, void* out,
                       int64_t ldo, void* stream);
 
+/* Many fp32 [R, C] (row stride ld) -> bf16 [C, >= R] (row stride ldo) transposes in one launch: the W^T operands of
+ * every trainable Linear after an optimizer step.  `jobs_dev` is a DEVICE array the caller fills once; job j owns the
+ * workgroups [tile0, tile0 + ceil(R / 64) * ceil(C / 64)), tile0 ascending from 0; total_tiles = their sum.  Elements
+ * out[c][r] with r >= R are not written. */
+typedef struct hk_transpose_job {
+    const void* x;
+    void* out;
+    int64_t ld, ldo;
+    int32_t R, C, tile0, pad_;
+} hk_transpose_job;
+int hk_transpose_f32_bf16_batch(const hk_transpose_job* jobs_dev, int32_t n_jobs, int32_t total_tiles, void* stream);
+
 /* Weight gradient of a Linear in one launch (what autograd computes for nn.Linear under tasks/train_it.py:63-80):
  *   dw[n][k] = sum_r dy[r][n] * x[r][k]   (fp32, row stride lddw, overwritten)
  *   db[n]    = sum_r dy[r][n]             (fp32, when db != NULL)

@@ -263,3 +263,30 @@ def test_wgrad_rejects_bad_shapes():
     with pytest.raises(RuntimeError, match="multiples of 128"):
         T.wgrad(dy, x)
     assert L.load().hk_wgrad_bf16(None, 0, None, None, None, 0, None, 0, 0, 0, None) == 1
+
+
+def test_batched_transpose_of_many_weights_in_one_launch():
+    """hk_transpose_f32_bf16_batch: the W^T operands of all Linear layers after an optimizer step in one launch (a job
+    table on the device).  Ragged sizes, two jobs sharing one output buffer side by side (the fused q|k|v weight)."""
+    import ctypes as C
+    from hawkeye_amd import lib as L
+    shapes = [(130, 70), (64, 64), (768, 200), (1, 5), (257, 129)]
+    xs = [_rand(s, 40 + i) for i, s in enumerate(shapes)]
+    outs = [torch.full((s[1], s[0] + 3), -7.0, dtype=torch.bfloat16, device=DEV) for s in shapes]
+    a, b = _rand((96, 80), 50), _rand((32, 80), 51)           # [a; b] fused along the output dim -> one [80, 128] W^T
+    fused = torch.zeros((80, 128), dtype=torch.bfloat16, device=DEV)
+    jobs, tile0 = [], 0
+    for x, o in zip(xs, outs):
+        jobs.append(L.HkTransposeJob(x.data_ptr(), o.data_ptr(), x.stride(0), o.stride(0), x.shape[0], x.shape[1], tile0, 0))
+        tile0 += -(-x.shape[0] // 64) * -(-x.shape[1] // 64)
+    for x, col in ((a, 0), (b, 96)):
+        jobs.append(L.HkTransposeJob(x.data_ptr(), fused.data_ptr() + 2 * col, 80, 128, x.shape[0], 80, tile0, 0))
+        tile0 += -(-x.shape[0] // 64) * 2
+    raw = (L.HkTransposeJob * len(jobs))(*jobs)
+    table = torch.frombuffer(bytearray(bytes(raw)), dtype=torch.uint8).to(DEV)
+    L.check(L.load().hk_transpose_f32_bf16_batch(table.data_ptr(), len(jobs), tile0, torch.cuda.current_stream().cuda_stream),
+            "hk_transpose_f32_bf16_batch")
+    for x, o in zip(xs, outs):
+        assert torch.equal(o[:, :x.shape[0]], x.t().to(torch.bfloat16))
+        assert (o[:, x.shape[0]:] == -7.0).all()                   # nothing written past R
+    assert torch.equal(fused, torch.cat([a, b]).t().to(torch.bfloat16))
