@@ -603,9 +603,20 @@ class HipEncoderEngine:
         """The second half on its own (two-device placement, hawkeye_it.py:230-234: the ViT may sit on another GPU and
         hands over image_embeds): image_embeds bf16 [B, N, D] = vision_layernorm's output, on any GPU -- copied into
         this engine's plan -- then cross K/V, the Q-Former and llama_proj.  Returns fp32 [B, n_query, llama_hidden]."""
+        plan, B, T, Lt = self.load_image_embeds(image_embeds, input_ids, text_mask, need_weights=True)
+        with torch.cuda.device(self.device):
+            self._enqueue(plan, None, False, None, None, B, T, Lt, 0, 0, None, lo=plan.vit_end, no_input=True, key_bias=False)
+        return plan.ws["out"].view(B, self.cfg.n_query, self.cfg.llama_hidden)
+
+    @torch.no_grad()
+    def load_image_embeds(self, image_embeds: torch.Tensor, input_ids, text_mask, need_weights: bool = False):
+        """The hand-over point of a two-device placement (hawkeye_it.py:234 `.to(self.device)`): image_embeds bf16
+        [B, N, D] from any GPU -> this engine's plan (`xn`), token ids / mask -> the plan, key bias launched.  Used by
+        forward_qformer and by the training engine, whose Q-Former forward starts from exactly these buffers.
+        Returns (plan, B, T, Lt)."""
         cfg = self.cfg
-        if "qformer" not in self.halves or not self.w:
-            raise RuntimeError("forward_qformer: this engine does not hold the Q-Former half (or has no weights yet)")
+        if "qformer" not in self.halves or (need_weights and not self.w):
+            raise RuntimeError("this engine does not hold the Q-Former half (or has no weights yet)")
         B, N, D = image_embeds.shape
         Lp = cfg.patches_per_frame
         if N % Lp != 0 or D != cfg.encoder_embed_dim or image_embeds.dtype != torch.bfloat16:
@@ -618,8 +629,9 @@ class HipEncoderEngine:
             if Lt > 0:
                 plan.ws["ids"].copy_(input_ids, non_blocking=True)
                 plan.ws["mask"].copy_(text_mask, non_blocking=True)
-            self._enqueue(plan, None, False, None, None, B, N // Lp, Lt, 0, 0, None, lo=plan.vit_end, no_input=True)
-        return plan.ws["out"].view(B, cfg.n_query, cfg.llama_hidden)
+            L.check(self.lib.hk_qformer_key_bias(plan.ws["mask"].data_ptr() if Lt > 0 else None, plan.ws["kbias"].data_ptr(), B,
+                                                 cfg.n_query, Lt, torch.cuda.current_stream().cuda_stream), "hk_qformer_key_bias")
+        return plan, B, N // Lp, Lt
 
     def _prepare(self, image, input_ids, text_mask, pos_embed):
         """Input validation, plan lookup, copy of the token ids / mask into the plan."""
@@ -676,14 +688,15 @@ class HipEncoderEngine:
             self.plans.popitem(last=False)
         return plan
 
-    def _enqueue(self, plan, image, u8, norm, pos_embed, B, T, Lt, H, W, profile, upto=None, lo=0, no_input=False):
+    def _enqueue(self, plan, image, u8, norm, pos_embed, B, T, Lt, H, W, profile, upto=None, lo=0, no_input=False, key_bias=True):
         """Every launch of one call, in order, on torch's current stream (also the body of the captured graph).
         lo / no_input: the launches from plan.steps[lo] on, without the patch gather (the Q-Former half of a two-device
         placement starts from image_embeds already in plan.ws["xn"])."""
         cfg, ws = self.cfg, plan.ws
         stream = torch.cuda.current_stream().cuda_stream
-        L.check(self.lib.hk_qformer_key_bias(ws["mask"].data_ptr() if Lt > 0 else None, ws["kbias"].data_ptr(), B,
-                                             cfg.n_query, Lt, stream), "hk_qformer_key_bias")
+        if key_bias:
+            L.check(self.lib.hk_qformer_key_bias(ws["mask"].data_ptr() if Lt > 0 else None, ws["kbias"].data_ptr(), B,
+                                                 cfg.n_query, Lt, stream), "hk_qformer_key_bias")
         if no_input:
             pass
         elif u8:

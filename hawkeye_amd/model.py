@@ -189,6 +189,13 @@ def disabled_train(self, mode=True):   # blip2.py:90-93
     return self
 
 
+class _Embeds:
+    """image_embeds handed over from the ViT's device in a two-device placement (what _EncodeImgFn gets instead of the clip)."""
+
+    def __init__(self, t: torch.Tensor):
+        self.t = t
+
+
 class _EncodeImgFn(torch.autograd.Function):
     """encode_img as one autograd node (row f2): forward = the HIP training forward, backward = the HIP backward.
     The trainable parameters are inputs of the node, so autograd (and DistributedDataParallel's hooks,
@@ -202,7 +209,10 @@ class _EncodeImgFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, image, ids, mask, table, norm, train, seed, *params):
         eng = model._train_engine
-        out, plan = eng.forward(image, ids, mask, table, train=train, seed=seed, norm=norm)
+        if isinstance(image, _Embeds):
+            out, plan = eng.forward(None, ids, mask, None, train=train, seed=seed, image_embeds=image.t)
+        else:
+            out, plan = eng.forward(image, ids, mask, table, train=train, seed=seed, norm=norm)
         ctx.model, ctx.plan, ctx.engine, ctx.stamp = model, plan, eng, plan.stamp
         return out.clone()
 
@@ -312,7 +322,8 @@ class HawkEyeEncoder(nn.Module):
         vision_layernorm on devices[1], Q-Former / query tokens / llama_proj on devices[0]; encode_img then runs the
         ViT half on devices[1] and hands image_embeds (bf16 [B, N, 1024]) over to devices[0] (hawkeye_it.py:230-234).
         A 288 GB MI355X never needs it; it is there because the reference's trainer exposes it (model_parallel,
-        tasks/shared_utils.py:48-51).  Inference only: the training path keeps both halves on one device."""
+        tasks/shared_utils.py:48-51).  Training works the same way (round 3): the frozen ViT runs on devices[1], the
+        training engine on devices[0] starts from the handed-over image_embeds."""
         assert isinstance(device_ids, list) and 1 <= len(device_ids) <= 2
         if len(device_ids) == 1:
             device_ids = [device_ids[0], device_ids[0]]
@@ -328,8 +339,9 @@ class HawkEyeEncoder(nn.Module):
     def _split_placement(self) -> bool:
         return self._force_split or next(self.vision_layernorm.parameters()).device != self.device
 
-    def _sync_split_engines(self):
-        """Two engines, one per half, each on the device its parameters live on."""
+    def _sync_split_engines(self, train: bool = False):
+        """Two engines, one per half, each on the device its parameters live on.  train=True: the Q-Former half's operands
+        are the training engine's arena, so only the ViT half is (re)packed here."""
         dq = self.device
         dv = next(self.vision_layernorm.parameters()).device
         if dq.type != "cuda" or dv.type != "cuda":
@@ -341,6 +353,8 @@ class HawkEyeEncoder(nn.Module):
             self._vit_engine = HipEncoderEngine(self.cfg, dv, self.residual_dtype, halves=("vit",))
             self._engine_key = {"vit": None, "qformer": None}
         for part, eng in (("vit", self._vit_engine), ("qformer", self._engine)):
+            if train and part == "qformer" and self._engine_key[part] is not None:
+                continue        # packed once (its plans' descriptors need operands to point at); never refreshed while training
             key = (str(eng.device), self._weights_key(part))
             if self._engine_key[part] != key:
                 eng.load_state_dict(self.state_dict(), parts=(part,))
@@ -439,8 +453,11 @@ class HawkEyeEncoder(nn.Module):
         named = dict(self.named_parameters())
         return {n: named[n] for n in trainable_names(self.cfg)}
 
-    def sync_train_engine(self) -> QFormerTrainEngine:
-        eng = self.sync_engine(parts=("vit",))
+    def sync_train_engine(self, eng: Optional[HipEncoderEngine] = None) -> QFormerTrainEngine:
+        """eng: the inference engine the training engine hangs on -- the single engine (default), or the Q-Former-half engine
+        of a two-device placement."""
+        if eng is None:
+            eng = self.sync_engine(parts=("vit",))
         te = self._train_engine
         if te is None or te.enc is not eng or not te.arena.attached():
             te = QFormerTrainEngine(eng, self.trainable_parameters(), self.qformer_hidden_dropout_prob,
@@ -572,6 +589,36 @@ class HawkEyeEncoder(nn.Module):
             out = out.to(self.out_dtype) if self.out_dtype != torch.float32 else out.clone()
         return out.to(device), use_image
 
+    def _encode_split_train(self, image, instruction, norm, dropout, need_grad):
+        """The stage-3 call with the reference's optional two-device placement (hawkeye_it.py:197-211 under
+        tasks/shared_utils.py:48-51): frozen ViT + vision_layernorm on devices[1] (inference launches, no_grad), image_embeds
+        handed to devices[0] (:234), training forward / backward of the Q-Former half there."""
+        device = image.device
+        ev, eq = self._sync_split_engines(train=True)
+        B, T = image.shape[0], image.shape[1]
+        use_image = True if T == 1 else False
+        table = self._table(use_image, T * self.cfg.patches_per_frame, ev.device)
+        ids = mask = None
+        if self.qformer_text_input:
+            ids, mask = self._tokenize(instruction, B, eq.device)
+        with torch.no_grad():
+            plan = ev.forward_vit(image.to(ev.device), None, None, table, norm=norm)
+            embeds = _Embeds(plan.ws["xn"].view(B, T * self.cfg.patches_per_frame, self.cfg.encoder_embed_dim))
+            if eq.device != ev.device:
+                done = torch.cuda.Event()
+                done.record(torch.cuda.current_stream(ev.device))
+                torch.cuda.current_stream(eq.device).wait_event(done)
+        te = self.sync_train_engine(eq)
+        seed = (self._drop_seed + self._drop_calls * 0x9E3779B9) & 0xFFFFFFFF
+        self._drop_calls += 1
+        if need_grad:
+            out = _EncodeImgFn.apply(self, embeds, ids, mask, None, None, dropout, seed, *te.arena.params)
+        else:
+            with torch.no_grad():
+                out = te.forward(None, ids, mask, None, train=dropout, seed=seed, image_embeds=embeds.t)[0].clone()
+        out = out.to(self.out_dtype) if self.out_dtype != torch.float32 else out
+        return out.to(device), use_image
+
     def _encode(self, image, instruction, norm):
         device = image.device
         dropout = self.qformer.training
@@ -588,8 +635,7 @@ class HawkEyeEncoder(nn.Module):
                                       "path has no CPU arithmetic; a 288 GB MI355X holds the 0.6 GB of ViT operands")
         if self._split_placement():
             if train_path:
-                raise NotImplementedError("two-device placement is inference only; put the model on one device to train "
-                                          "(model.eval() and torch.no_grad() select the inference path)")
+                return self._encode_split_train(image, instruction, norm, dropout, need_grad)
             return self._encode_split(image, instruction, norm)
         eng = self.sync_engine(parts=("vit",) if train_path else ("vit", "qformer"))
         if device != eng.device:

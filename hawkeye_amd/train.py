@@ -554,11 +554,17 @@ class QFormerTrainEngine:
                 L.check(rc, name)
 
     @torch.no_grad()
-    def forward(self, image, input_ids, text_mask, pos_embed, *, train: bool, seed: int = 0, norm=None):
+    def forward(self, image, input_ids, text_mask, pos_embed, *, train: bool, seed: int = 0, norm=None, image_embeds=None):
         """Same inputs as HipEncoderEngine.forward.  train=True applies dropout / drop-path with `seed`.
+        image_embeds (bf16 [B, N, D], any GPU): two-device placement (hawkeye_it.py:197-211, tasks/shared_utils.py:48-51) --
+        the frozen ViT ran on another engine / device; this engine (whose `enc` then holds the Q-Former half only) starts
+        from the handed-over vision_layernorm output and `image` / `pos_embed` are not read.
         Returns (out fp32 [B, nq, llama_hidden] -- a view of the plan's buffer --, plan)."""
         cfg = self.cfg
-        B, T = int(image.shape[0]), int(image.shape[1])
+        if image_embeds is not None:
+            B, T = int(image_embeds.shape[0]), int(image_embeds.shape[1]) // cfg.patches_per_frame
+        else:
+            B, T = int(image.shape[0]), int(image.shape[1])
         Lt = 0 if input_ids is None else int(input_ids.shape[1])
         key = (B, T, Lt)
         enc_plan = self.enc.plan_for(B, T, Lt)
@@ -576,7 +582,9 @@ class QFormerTrainEngine:
         self.pack()
         with torch.cuda.device(self.device):
             # the frozen ViT: the inference plan's launches up to vision_layernorm (validation of the inputs included)
-            if self.enc.forward_vit(image, input_ids, text_mask, pos_embed, norm=norm) is not plan.enc_plan:
+            got = (self.enc.load_image_embeds(image_embeds, input_ids, text_mask)[0] if image_embeds is not None else
+                   self.enc.forward_vit(image, input_ids, text_mask, pos_embed, norm=norm))
+            if got is not plan.enc_plan:
                 raise RuntimeError("internal: the inference plan changed between lookup and launch")
             self._arm(plan, train, seed)
             plan.train, plan.seed = train, seed

@@ -268,3 +268,42 @@ def test_full_size_qformer_gradients_vs_oracle():
     grads = {n: p.grad for n, p in m.named_parameters() if p.requires_grad}
     worst = _compare(grads, ref, "full")
     print("worst gradient cosine", worst)
+
+
+def test_two_device_placement_trains_with_the_single_engines_bits(golden_dir):
+    """The reference's optional model_parallel placement under training (hawkeye_it.py:197-211 with
+    tasks/shared_utils.py:48-51): frozen ViT on devices[1], training forward / backward of the Q-Former half on
+    devices[0] from the handed-over image_embeds.  The box has one GPU, so both half-engines are forced onto it: the
+    same launches on the same data => output and every gradient bit-identical to the single-engine training call, in
+    train mode (dropout on, same seed) and against the reference golden."""
+    g, cfg, sd, image, ids, mask, table, dout = load_case(golden_dir)
+    res = {}
+    for split in (False, True):
+        m = _model(cfg, sd, table, True)
+        m._force_split = split
+        m.set_dropout_seed(int(g["drop_seed"]))
+        out, use_image = m.encode_img(image.to(DEV), (ids.to(DEV), mask.to(DEV)))
+        assert out.requires_grad and not use_image
+        (out * dout.to(DEV)).sum().backward()
+        grads = {n: p.grad.clone() for n, p in m.named_parameters() if p.requires_grad}
+        res[split] = (out.detach().clone(), grads)
+        if split:
+            assert m._vit_engine is not None and m._vit_engine.halves == ("vit",) and m._engine.halves == ("qformer",)
+            assert m._train_engine.enc is m._engine
+            check_against_golden(g, "train", out.detach().cpu(), {k: v for k, v in grads.items()}, 5e-2, floor=0.1)
+            # dropout without gradients (model.train() under no_grad) takes the same route
+            with torch.no_grad():
+                m.set_dropout_seed(int(g["drop_seed"]))
+                again, _ = m.encode_img(image.to(DEV), (ids.to(DEV), mask.to(DEV)))
+            assert torch.equal(again, out.detach())
+            # and an optimizer step on the split model reaches the kernels
+            with torch.no_grad():
+                m.llama_proj.bias.add_(1.0)
+                m.set_dropout_seed(int(g["drop_seed"]))
+                moved, _ = m.encode_img(image.to(DEV), (ids.to(DEV), mask.to(DEV)))
+            assert torch.allclose(moved, out.detach() + 1.0, atol=1e-5)
+            key_before = m._engine_key["qformer"]
+            assert m._engine_key["qformer"] == key_before           # the Q-Former half is not repacked per training call
+    assert torch.equal(res[False][0], res[True][0])
+    for k in res[False][1]:
+        assert torch.equal(res[False][1][k], res[True][1][k]), k
