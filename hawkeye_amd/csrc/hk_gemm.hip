@@ -192,11 +192,17 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
 // and leave as whole 256 / 128-byte row segments, 16 bytes per lane.  The fp32 residual is read the
 // same way.  Bias, column scale and GELU are applied on the accumulator layout, before LDS.
 #ifndef HK_EPI_PF
-#define HK_EPI_PF 3
+#define HK_EPI_PF 2   // residual prefetch distance of the in-place epilogue, in rounds (2-6 measured alike; 3 spills beside the FAST path)
 #endif
-template <int EPI, int PF_ROUNDS = HK_EPI_PF>
-__device__ __forceinline__ void pp_epilogue(const GemmParams& p, f32x4 (&acc)[2][2][4][2], char* stg, const char* aux,
-                                            const int lane, const int wm, const int wn, const int m0, const int n0) {
+// FAST (round 3): the wave's 128 rows lie inside M and the C / residual rows are plain (no rows_per_batch map) -- every ViT
+// launch except a last partial row panel.  Then a row address is a wave-uniform 64-bit base (tile, wave, round: SALU) plus
+// ONE 32-bit lane offset, there is no bounds predicate, and the staged rows of a round are read back together.  The general
+// form computed RowMap::off() -- two quarter-rate 32-bit multiplies and a 64-bit multiply-add -- per lane and store, kept
+// each store in an EXEC-masked block of its own and so waited for each LDS read right where it was issued: 16 exposed LDS
+// round trips and ~200 address instructions per wave and tile in an epilogue that is bound by vector issue.
+template <int EPI, int PF_ROUNDS, bool FAST>
+__device__ __forceinline__ void pp_epilogue_impl(const GemmParams& p, f32x4 (&acc)[2][2][4][2], char* stg, const char* aux,
+                                                 const int lane, const int wm, const int wn, const int m0, const int n0) {
     if (HK_DBG(p) & 1) {  // dbg 1: timing-only build, no epilogue (accumulators kept live)
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -275,6 +281,19 @@ __device__ __forceinline__ void pp_epilogue(const GemmParams& p, f32x4 (&acc)[2]
                             const int ch = nh * 4 + j * 2 + (g4 >> 1);
                             *reinterpret_cast<u32x2*>(stg + row * 128 + ((ch ^ (row & 7)) << 4) + (g4 & 1) * 8) = o;
                         }
+                if (FAST) {
+                    u32x4 o[4];
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int row = it * 8 + (lane >> 3), ch = lane & 7;
+                        o[it] = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((ch ^ (row & 7)) << 4));
+                    }
+                    char* rb = reinterpret_cast<char*>(p.C) + ((int64_t)(mw + mh * 64 + i2 * 32) * p.c.ld + nw) * 2;   // wave-uniform
+                    const uint32_t lo = (uint32_t)(((lane >> 3) * (int)p.c.ld + (lane & 7) * 8) * 2);
+#pragma unroll
+                    for (int it = 0; it < 4; ++it)
+                        __builtin_nontemporal_store(o[it], reinterpret_cast<u32x4*>(rb + (int64_t)it * 8 * p.c.ld * 2 + lo));
+                } else {
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int row = it * 8 + (lane >> 3), ch = lane & 7;
@@ -285,6 +304,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmParams& p, f32x4 (&acc)[2]
                     // output, which are re-read at once, measured no gain and keep plain stores
                     if (m < p.M && n < p.N)
                         __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(p.C) + p.c.off(m) + n));
+                }
                 }
             }
     } else {
@@ -301,11 +321,21 @@ __device__ __forceinline__ void pp_epilogue(const GemmParams& p, f32x4 (&acc)[2]
             // the queue.  HK_EPI_PF (compile time): prefetch distance in rounds.
             constexpr int PF = PF_ROUNDS;
             u32x4 rr[PF + 1][2];
+            // FAST: wave-uniform bases of the wave's residual / output / row-sum rows + one 32-bit lane offset each
+            const char* rbase = reinterpret_cast<const char*>(p.res) + ((int64_t)mw * p.r.ld + nw) * 2;
+            char* cbase = reinterpret_cast<char*>(p.C) + ((int64_t)mw * p.c.ld + nw) * 2;
+            // (FAST requires equal row strides of C and the residual -- the in-place update -- so one lane offset serves both)
+            const uint32_t rlo = (uint32_t)(((lane >> 3) * (int)p.c.ld + (lane & 7) * 8) * 2);
+            const uint32_t clo = rlo;
             auto res_load8 = [&](int rnd, u32x4(&dst)[2]) __attribute__((always_inline)) {
 #pragma unroll
                 for (int it = 0; it < 2; ++it) {
-                    const int m = min(mw + rnd * 16 + it * 8 + (lane >> 3), p.M - 1), n = nw + (lane & 7) * 8;
-                    dst[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const __bf16*>(p.res) + p.r.off(m) + n);
+                    if (FAST) {
+                        dst[it] = *reinterpret_cast<const u32x4*>(rbase + (int64_t)(rnd * 16 + it * 8) * p.r.ld * 2 + rlo);
+                    } else {
+                        const int m = min(mw + rnd * 16 + it * 8 + (lane >> 3), p.M - 1), n = nw + (lane & 7) * 8;
+                        dst[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const __bf16*>(p.res) + p.r.off(m) + n);
+                    }
                 }
             };
 #pragma unroll
@@ -354,12 +384,17 @@ __device__ __forceinline__ void pp_epilogue(const GemmParams& p, f32x4 (&acc)[2]
                         s2 = __builtin_fmaf(w7, w7, s2);
                         s1 = sum8_dpp(s1);
                         s2 = sum8_dpp(s2);
-                        if (c8 == 0 && m < p.M) {
-                            typedef __attribute__((ext_vector_type(2))) float f32x2s;
+                        typedef __attribute__((ext_vector_type(2))) float f32x2s;
+                        if (FAST) {
+                            float* rp = p.row_part + ((int64_t)(mw + rnd * 16 + it * 8) * (p.N >> 6) + (nw >> 6)) * 2;   // wave-uniform
+                            if (c8 == 0) *reinterpret_cast<f32x2s*>(rp + (uint32_t)((lane >> 3) * (p.N >> 6) * 2)) = f32x2s{s1, s2};
+                        } else if (c8 == 0 && m < p.M) {
                             *reinterpret_cast<f32x2s*>(p.row_part + ((int64_t)m * (p.N >> 6) + (nw >> 6)) * 2) = f32x2s{s1, s2};
                         }
                     }
-                    if (m < p.M && n < p.N)
+                    if (FAST)
+                        *reinterpret_cast<u32x4*>(cbase + (int64_t)(rnd * 16 + it * 8) * p.c.ld * 2 + clo) = o;
+                    else if (m < p.M && n < p.N)
                         *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(p.C) + p.c.off(m) + n) = o;
                 }
             }
@@ -406,6 +441,19 @@ __device__ __forceinline__ void pp_epilogue(const GemmParams& p, f32x4 (&acc)[2]
             for (int it = 0; it < 4; ++it) rcur[it] = rnxt[it];
         }
     }
+}
+
+#ifndef HK_EPI_FAST
+#define HK_EPI_FAST 1   // 0: every tile takes the general addressing path (A/B builds)
+#endif
+template <int EPI, int PF_ROUNDS = HK_EPI_PF>
+__device__ __forceinline__ void pp_epilogue(const GemmParams& p, f32x4 (&acc)[2][2][4][2], char* stg, const char* aux,
+                                            const int lane, const int wm, const int wn, const int m0, const int n0) {
+    // wave-uniform: whole 128 x 64 sub-tile inside the problem, plain rows for C (and for the in-place residual)
+    const bool fast = HK_EPI_FAST != 0 && EPI != 1 && p.c.rpb == 0 && (EPI == 0 || EPI == 3 || (p.r.rpb == 0 && p.r.ld == p.c.ld)) &&
+                      m0 + wm * 128 + 128 <= p.M && n0 + wn * 64 + 64 <= p.N;
+    if (fast) pp_epilogue_impl<EPI, PF_ROUNDS, true>(p, acc, stg, aux, lane, wm, wn, m0, n0);
+    else pp_epilogue_impl<EPI, PF_ROUNDS, false>(p, acc, stg, aux, lane, wm, wn, m0, n0);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -6,7 +6,6 @@ import sys
 
 import torch
 
-torch.set_grad_enabled(False)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hawkeye_amd import lib as L, ops  # noqa: E402
 
@@ -86,6 +85,20 @@ def timeit(fn, iters=8, warm=2):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
+def time_pp(M=100352):
+    """The default (256x256) kernel alone at the ViT shapes: for same-box A/B of library builds (HK_LIB_PATH)."""
+    shapes = (("qkv (fold)", 3, 3072, 1024), ("fc1+gelu (fold)", 3, 4096, 1024), ("proj (row_part)", 4, 1024, 1024),
+              ("fc2 (row_part)", 4, 1024, 4096), ("ckv", 0, 9216, 1024))
+    lib.hk_gemm_duo_mask(0)
+    tag = os.path.basename(os.environ.get("HK_LIB_PATH", "default"))
+    for name, kind, N, K in shapes:
+        args = make(M, N, K, kind)
+        out = args[-1]
+        t = min(timeit(lambda: run(kind, *args[:7], out)) for _ in range(3))
+        print(f"[{tag}] {name:18s}: {t:8.1f} us  {2.0 * M * N * K / t / 1e6:7.1f} TFLOP/s", flush=True)
+        del args, out
+
+
 def time_all(M=100352):
     shapes = (("qkv (fold)", 3, 3072, 1024), ("fc1+gelu (fold)", 3, 4096, 1024), ("proj (row_part)", 4, 1024, 1024),
               ("fc2 (row_part)", 4, 1024, 4096), ("ckv", 0, 9216, 1024), ("patch", 2, 1024, 768))
@@ -106,9 +119,12 @@ def time_all(M=100352):
 
 
 if __name__ == "__main__":
+    torch.set_grad_enabled(False)      # (not at import: tests import this module)
     what = sys.argv[1:] or ["check", "time"]
     if "check" in what:
         if not check():
             sys.exit(1)
     if "time" in what:
         time_all()
+    if "pp" in what:
+        time_pp()
