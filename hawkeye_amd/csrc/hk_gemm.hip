@@ -18,6 +18,7 @@
 // Pipeline: two LDS stages; the loads of K-tile t+1 are issued before the MFMAs of tile t and
 // retired by one vmcnt(0)+barrier per K-tile.
 #include <stdlib.h>
+#include <type_traits>
 #include "hk_common.h"
 
 #ifndef HK_DUO_PF
@@ -589,6 +590,10 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
                     for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
     zero_acc();
+#ifndef HK_ZERO_C
+#define HK_ZERO_C 1
+#endif
+    constexpr bool ZC_AFTER = HK_ZERO_C != 0 && (EPI == 2 || EPI == 4);   // see the K loop
 
     auto load_a = [&](int buf, int mh) {
         const __bf16* s0 = lds + buf * BUF + a_base + mh * 64 * BK;
@@ -606,6 +611,11 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
             wb[1][j] = *reinterpret_cast<const bf16x8*>(s0 + j * 16 * BK + foff1);
         }
     };
+    // FIRST: the first K-tile of an output tile multiplies into a zero C operand (an inline constant of the MFMA) instead of
+    // into accumulators that 128 v_mov per wave and tile would have had to clear first (HK_ZERO_C=0: A/B build with the clear)
+#ifndef HK_ZERO_C
+#define HK_ZERO_C 1
+#endif
 #define HK_MMA(MH, NH)                                                                                      \
     do {                                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
@@ -615,7 +625,8 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
         __builtin_amdgcn_s_setprio(1);                                                                      \
         _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int i = 0; i < 4; ++i)      \
             _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[MH][NH][i][j] =                               \
-                __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[kk][j], xa[kk][i], acc[MH][NH][i][j], 0, 0, 0);  \
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[kk][j], xa[kk][i],                               \
+                    (FIRST && kk == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[MH][NH][i][j], 0, 0, 0);           \
         __builtin_amdgcn_s_setprio(0);                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
         HK_BAR();                                                                                           \
@@ -669,7 +680,8 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
             tile_coords(c0 + jb + ti * nbx, p.nbm, p.nbn, p.gm, tm_, tn_);
             glds16_v(p.row_stats + 2 * ((int64_t)tm_ * 256 + wm * 128 + 2 * lane), stg);
         }
-        for (int t = 0; t < KT; ++t) {
+        auto ktile = [&](auto first_) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first_)::value;
             // phase 1
             load_a(buf, 0);
             load_w(buf, 0);
@@ -692,6 +704,16 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
             }
             HK_MMA(1, 0);
             buf ^= 1;
+        };
+        // measured per epilogue kind on one box (zc0 / zc1 builds interleaved): proj 245.5 -> 241.0 us, fc2 681.7 -> 672.4; qkv
+        // 562.5 -> 560.8 (noise), fc1+GELU 766.0 -> 773.4 (slower: that instantiation sits at 256 registers with the peeled copy
+        // of the K-tile body) -- so only the in-place residual epilogues take the zero-C form
+        constexpr bool ZC = HK_ZERO_C != 0 && (EPI == 2 || EPI == 4);
+        if constexpr (ZC) {
+            ktile(std::true_type{});
+            for (int t = 1; t < KT; ++t) ktile(std::false_type{});
+        } else {
+            for (int t = 0; t < KT; ++t) ktile(std::false_type{});
         }
         const int lid = c0 + jb + ti * nbx;
         if (trc && tid == 0 && ti < 31) trc[2 + 2 * ti] = __builtin_amdgcn_s_memrealtime();
@@ -699,7 +721,7 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
         tile_coords(lid, p.nbm, p.nbn, p.gm, tm, tn);
         epilogue(tm * 256, tn * 256);
         if (trc && tid == 0 && ti < 31) trc[3 + 2 * ti] = __builtin_amdgcn_s_memrealtime();
-        zero_acc();
+        if constexpr (!ZC_AFTER) zero_acc();
     }
     if (wm == 0) HK_BAR();  // equalise the barrier count of the two groups
 #undef HK_MMA
