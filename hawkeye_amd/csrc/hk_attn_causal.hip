@@ -29,6 +29,12 @@ struct CausalParams {
     int nqb, causal;
 };
 
+#ifndef HK_CAUSAL_OCC
+#define HK_CAUSAL_OCC 2   // waves per SIMD the register allocation targets (2: two workgroups per CU)
+#endif
+#ifndef HK_CAUSAL_LPT
+#define HK_CAUSAL_LPT 1
+#endif
 constexpr int QB = 128;
 constexpr int KT = 64;
 constexpr float NEG_BIG = -1.0e30f;
@@ -40,7 +46,7 @@ __device__ __forceinline__ void half_swap(float x, float& a, float& b) {
 }
 
 template <int HD, bool HAS_BIAS>
-__global__ __launch_bounds__(256, 1) void hk_attn_causal_kernel(const CausalParams p) {
+__global__ __launch_bounds__(256, HK_CAUSAL_OCC) void hk_attn_causal_kernel(const CausalParams p) {
     constexpr int ROWB = HD * 2;       // bytes per key row in LDS
     constexpr int CH = HD / 8;         // 16-byte chunks per row
     constexpr int NKS = HD / 16;       // k-steps of S^T
@@ -55,8 +61,18 @@ __global__ __launch_bounds__(256, 1) void hk_attn_causal_kernel(const CausalPara
     const int r = lane & 31;
     const int h = lane >> 5;
 
+#if HK_CAUSAL_LPT
+    // longest-first over the whole grid: every (batch, head)'s last query block is dispatched before any shorter
+    // one, so the short blocks fill the tail of the launch. A (batch, head)'s blocks sit nbh apart in blockIdx,
+    // a multiple of 8 for the shapes served, so they share an XCD's L2 for K and V.
+    const int nbh = p.B * p.H;
+    const int rank = blockIdx.x / nbh;
+    const int bh = blockIdx.x - rank * nbh;
+    const int qb = p.nqb - 1 - rank;
+#else
     const int bh = blockIdx.x / p.nqb;
     const int qb = p.nqb - 1 - (blockIdx.x - bh * p.nqb);   // longest (last) query blocks first
+#endif
     const int b = bh / p.H;
     const int head = bh - b * p.H;
     const int q0 = qb * QB + wave * 32;
