@@ -457,6 +457,89 @@ __device__ __forceinline__ void pp_epilogue(const GemmParams& p, f32x4 (&acc)[2]
     else pp_epilogue_impl<EPI, PF_ROUNDS, false>(p, acc, stg, aux, lane, wm, wn, m0, n0);
 }
 
+// ---- per-quadrant epilogue of the 256x256 kernel (HK_EPI_QUAD) ----
+// A wave's 64x32 output quadrant (MH, NH) is final after phase p of a tile's LAST K-tile and is not touched again before
+// phase p of the next tile's first K-tile.  Its epilogue therefore runs in the read / stage section of the phase that
+// follows, i.e. while the partner wave of the SIMD (the other M-group, one barrier behind or ahead) is inside its
+// 16-MFMA cluster: the vector math, the LDS transpose and the store issue of the epilogue then share the SIMD with matrix
+// instructions instead of leaving the matrix pipe idle for a whole epilogue per tile.
+// Slab use (4 KB per wave): bytes 0..1535 keep the tile's epilogue operands (row statistics, bias, column sums of W) for
+// all four quadrants; the transpose goes through bytes 2048..4095, 32 rows x 64 B at a time (two rounds per quadrant):
+// 16-byte chunk c of row r at chunk c ^ (((r >> 2) & 1) << 1), which spreads the 16 rows x 32 B of one ds_write_b64 over
+// all banks.  Stores are 16 rows x 64 B per instruction; the other 64-byte half of each 128-byte line follows one
+// quadrant later.  FAST-form addressing only (whole sub-tile inside the problem, plain rows): the caller checks.
+// MEASURED SLOWER, so off by default (HK_EPI_QUAD=1 builds it; same bits as the ordinary epilogue, tools/ab_quad.sh,
+// profiles/r03_epi_quad_ab.txt): qkv 567 -> 595 us, fc1+GELU 797 -> 817, cross K/V 1557 -> 1620, step 84.6 -> 87.3 ms.  Timing probes of
+// the same form: without its global stores 558 / 780 / 1461, without stores and LDS transpose (vector math only) 535 / 760 /
+// 1386 -- against ~455 for qkv with no epilogue at all, i.e. even the bare vector math costs ~4 us per tile when it is
+// interleaved, three times what it costs in the ordinary epilogue: a read section is already as long as the partner's MFMA
+// cluster (its fragment reads share the LDS with the other group's), every barrier interval of the last K-tile grows by the
+// section's vector work, and the two groups' sections -- concurrent in the ordinary epilogue -- are serialised by the barriers.
+#ifndef HK_EPI_QUAD
+#define HK_EPI_QUAD 0
+#endif
+
+template <int EPI, int MH, int NH>
+__device__ __forceinline__ void pp_quad_epilogue(const GemmParams& p, f32x4 (&acc)[2][2][4][2], char* stg, const int lane,
+                                                 const int wm, const int wn, const int m0, const int n0) {
+    static_assert(EPI == 0 || EPI == 3, "quadrant epilogue: bf16-out kinds");
+    constexpr bool FOLD = EPI == 3;
+    typedef __attribute__((ext_vector_type(2))) float f32x2s;
+    const int r16 = lane & 15, g4 = lane >> 4;
+    f32x4 bias[2], cc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        bias[j] = p.bias != nullptr ? *reinterpret_cast<const f32x4*>(stg + 1024 + (NH * 32 + j * 16 + g4 * 4) * 4)
+                                    : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (FOLD) cc[j] = *reinterpret_cast<const f32x4*>(stg + 1280 + (NH * 32 + j * 16 + g4 * 4) * 4);
+    }
+    char* tr = stg + 2048;
+    const int nq = n0 + wn * 64 + NH * 32;
+    char* rb = reinterpret_cast<char*>(p.C) + ((int64_t)(m0 + wm * 128 + MH * 64) * p.c.ld + nq) * 2;   // wave-uniform
+    const uint32_t lo = (uint32_t)(((lane >> 2) * (int)p.c.ld + (lane & 3) * 8) * 2);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            const int i = half * 2 + ii;
+            float rs = 1.f, rm = 0.f;
+            if (FOLD) {
+                const f32x2s st = *reinterpret_cast<const f32x2s*>(stg + (MH * 64 + i * 16 + r16) * 8);
+                rs = st[1];
+                rm = st[1] * st[0];
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x4 v = acc[MH][NH][i][j];
+                if (FOLD) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], rs, __builtin_fmaf(-rm, cc[j][e], bias[j][e]));
+                } else {
+                    v += bias[j];
+                }
+                if (p.scale_cols != 0 && nq + j * 16 + g4 * 4 < p.scale_cols) v *= p.scale;
+                if (p.act == HK_ACT_GELU_ERF) v = gelu_erf4_bf16dst(v);
+                u32x2 o;
+                o[0] = pack_bf16x2(v[0], v[1]);
+                o[1] = pack_bf16x2(v[2], v[3]);
+                const int row = ii * 16 + r16;
+                const int ch = j * 2 + (g4 >> 1);
+                *reinterpret_cast<u32x2*>(tr + row * 64 + ((ch ^ (((row >> 2) & 1) << 1)) << 4) + (g4 & 1) * 8) = o;
+                acc[MH][NH][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        u32x4 o[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int row = it * 16 + (lane >> 2), c = lane & 3;
+            o[it] = *reinterpret_cast<const u32x4*>(tr + row * 64 + ((c ^ (((row >> 2) & 1) << 1)) << 4));
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+            __builtin_nontemporal_store(o[it], reinterpret_cast<u32x4*>(rb + (int64_t)(half * 32 + it * 16) * p.c.ld * 2 + lo));
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // 256x256x64 "ping-pong" kernel: 8 waves as 2 (M) x 4 (N); the two M-groups of waves run one
 // barrier apart, so on every SIMD one wave is inside a 16-MFMA cluster while its partner reads
@@ -594,6 +677,7 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
 #define HK_ZERO_C 1
 #endif
     constexpr bool ZC_AFTER = HK_ZERO_C != 0 && (EPI == 2 || EPI == 4);   // see the K loop
+    constexpr bool QUAD = HK_EPI_QUAD != 0 && (EPI == 0 || EPI == 3);     // quadrant epilogues inside the last K-tile
 
     auto load_a = [&](int buf, int mh) {
         const __bf16* s0 = lds + buf * BUF + a_base + mh * 64 * BK;
@@ -709,19 +793,62 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
         // 562.5 -> 560.8 (noise), fc1+GELU 766.0 -> 773.4 (slower: that instantiation sits at 256 registers with the peeled copy
         // of the K-tile body) -- so only the in-place residual epilogues take the zero-C form
         constexpr bool ZC = HK_ZERO_C != 0 && (EPI == 2 || EPI == 4);
+        const int lid = c0 + jb + ti * nbx;
+        int tm, tn;
+        tile_coords(lid, p.nbm, p.nbn, p.gm, tm, tn);
+        if constexpr (QUAD) {
+            // wave-uniform: the wave's whole sub-tile inside the problem and plain C rows -> its quadrants leave during the
+            // last K-tile; otherwise the ordinary epilogue after it.  Both forms pass the same barriers.
+            // (two K-tiles at least: the tile's epilogue operands are retired by the first K-tile's counted wait)
+            const bool fastq = KT >= 2 && p.c.rpb == 0 && tm * 256 + wm * 128 + 128 <= p.M && tn * 256 + wn * 64 + 64 <= p.N && HK_DBG(p) == 0;
+            const int kt_main = fastq ? KT - 1 : KT;
+            for (int t = 0; t < kt_main; ++t) ktile(std::false_type{});
+            if (fastq) {
+                const int m0 = tm * 256, n0 = tn * 256;
+                constexpr bool FIRST = false;
+                // phase 1
+                load_a(buf, 0);
+                load_w(buf, 0);
+                stage(1);
+                HK_MMA(0, 0);
+                // phase 2: + epilogue of q(0,0)
+                load_w(buf, 1);
+                stage(2);
+                pp_quad_epilogue<EPI, 0, 0>(p, acc, stg, lane, wm, wn, m0, n0);
+                HK_MMA(0, 1);
+                // phase 3: + epilogue of q(0,1)
+                load_a(buf, 1);
+                stage(3);
+                pp_quad_epilogue<EPI, 0, 1>(p, acc, stg, lane, wm, wn, m0, n0);
+                HK_MMA(1, 1);
+                // phase 4: the counted wait leaves this phase's 2 LDS-DMA and the 4 stores of q(0,1) in flight; + epilogue of q(1,1)
+                load_w(buf, 0);
+                if (stage(0)) {
+                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                pp_quad_epilogue<EPI, 1, 1>(p, acc, stg, lane, wm, wn, m0, n0);
+                HK_MMA(1, 0);
+                buf ^= 1;
+                // q(1,0): in front of the next tile's first read section (the partner group is one barrier behind / ahead)
+                pp_quad_epilogue<EPI, 1, 0>(p, acc, stg, lane, wm, wn, m0, n0);
+            } else {
+                pp_epilogue_impl<EPI, HK_EPI_PF, false>(p, acc, stg, stg, lane, wm, wn, tm * 256, tn * 256);
+                zero_acc();
+            }
+        } else {
         if constexpr (ZC) {
             ktile(std::true_type{});
             for (int t = 1; t < KT; ++t) ktile(std::false_type{});
         } else {
             for (int t = 0; t < KT; ++t) ktile(std::false_type{});
         }
-        const int lid = c0 + jb + ti * nbx;
         if (trc && tid == 0 && ti < 31) trc[2 + 2 * ti] = __builtin_amdgcn_s_memrealtime();
-        int tm, tn;
-        tile_coords(lid, p.nbm, p.nbn, p.gm, tm, tn);
         epilogue(tm * 256, tn * 256);
         if (trc && tid == 0 && ti < 31) trc[3 + 2 * ti] = __builtin_amdgcn_s_memrealtime();
         if constexpr (!ZC_AFTER) zero_acc();
+        }
     }
     if (wm == 0) HK_BAR();  // equalise the barrier count of the two groups
 #undef HK_MMA

@@ -72,6 +72,25 @@ def check():
     return ok
 
 
+def digest():
+    """Hashes of the default kernel's outputs at shapes with whole, partial and mapped tiles: two library builds
+    (HK_LIB_PATH) that should produce the same bits print the same lines."""
+    import hashlib
+    lib.hk_gemm_duo_mask(0)
+    for kind in (0, 3, 2, 4, 1):
+        for (M, N, K) in ((25088, 1024 if kind in (2, 4) else 3072, 1024), (25088 + 77, 1024, 4096 if kind != 3 else 1024),
+                          (16384, 4096 if kind in (0, 3) else 1024, 1024), (32768 + 256, 1024, 768), (512, 4096, 64), (1024, 2048, 128)):
+            args = make(M, N, K, kind)
+            out = args[-1].clone()
+            rp = args[6].clone() if args[6] is not None else None
+            run(kind, *args[:6], rp, out)
+            torch.cuda.synchronize()
+            h = hashlib.sha256(out.view(torch.uint8).cpu().numpy().tobytes())
+            if rp is not None:
+                h.update(rp.cpu().numpy().tobytes())
+            print(f"DIGEST epi {kind} M={M} N={N} K={K}: {h.hexdigest()[:24]}", flush=True)
+
+
 def timeit(fn, iters=8, warm=2):
     for _ in range(warm):
         fn()
@@ -126,5 +145,7 @@ if __name__ == "__main__":
             sys.exit(1)
     if "time" in what:
         time_all()
+    if "digest" in what:
+        digest()
     if "pp" in what:
         time_pp()
