@@ -201,8 +201,9 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
 // form computed RowMap::off() -- two quarter-rate 32-bit multiplies and a 64-bit multiply-add -- per lane and store, kept
 // each store in an EXEC-masked block of its own and so waited for each LDS read right where it was issued: 16 exposed LDS
 // round trips and ~200 address instructions per wave and tile in an epilogue that is bound by vector issue.
-template <int EPI, int PF_ROUNDS, bool FAST>
-__device__ __forceinline__ void pp_epilogue_impl(const GemmParams& p, f32x4 (&acc)[2][2][4][2], char* stg, const char* aux,
+// NI: 16-row blocks per M-half of the wave's sub-tile (4: 128 rows, the 256-row tile; 3: 96 rows, the 192-row tile).
+template <int EPI, int PF_ROUNDS, bool FAST, int NI = 4>
+__device__ __forceinline__ void pp_epilogue_impl(const GemmParams& p, f32x4 (&acc)[2][2][NI][2], char* stg, const char* aux,
                                                  const int lane, const int wm, const int wn, const int m0, const int n0) {
     if (HK_DBG(p) & 1) {  // dbg 1: timing-only build, no epilogue (accumulators kept live)
 #pragma unroll
@@ -210,7 +211,7 @@ __device__ __forceinline__ void pp_epilogue_impl(const GemmParams& p, f32x4 (&ac
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < NI; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[a][b][i][j]));
         return;
@@ -227,16 +228,16 @@ __device__ __forceinline__ void pp_epilogue_impl(const GemmParams& p, f32x4 (&ac
                               ? *reinterpret_cast<const f32x4*>(aux + 1024 + (nh * 32 + j * 16 + (lane >> 4) * 4) * 4)
                               : f32x4{0.f, 0.f, 0.f, 0.f};
     constexpr bool FOLD = EPI == 3;
-    float rs[2][4], rm[2][4];
+    float rs[2][NI], rm[2][NI];
     f32x4 cc[2][2];
     if (FOLD) {
         typedef __attribute__((ext_vector_type(2))) float f32x2s;
 #pragma unroll
         for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                // (mean, rstd) of row mh*64 + i*16 + (lane & 15) of the wave's 128: staged by the main loop
-                const f32x2s st = *reinterpret_cast<const f32x2s*>(aux + (mh * 64 + i * 16 + (lane & 15)) * 8);
+            for (int i = 0; i < NI; ++i) {
+                // (mean, rstd) of row (mh*NI + i)*16 + (lane & 15) of the wave's 32 NI: staged by the main loop
+                const f32x2s st = *reinterpret_cast<const f32x2s*>(aux + ((mh * NI + i) * 16 + (lane & 15)) * 8);
                 rs[mh][i] = st[1];
                 rm[mh][i] = st[1] * st[0];
             }
@@ -259,22 +260,21 @@ __device__ __forceinline__ void pp_epilogue_impl(const GemmParams& p, f32x4 (&ac
         if (p.act == HK_ACT_GELU_ERF) v = (EPI == 0 || EPI == 3 || !p.out_f32) ? gelu_erf4_bf16dst(v) : gelu_erf4(v);
         return v;
     };
-    const int mw = m0 + wm * 128;  // first row / column of this wave's sub-tile
+    const int mw = m0 + wm * (32 * NI);  // first row / column of this wave's sub-tile
     const int nw = n0 + wn * 64;
     const int r16 = lane & 15, g4 = lane >> 4;
     if (EPI == 0 || EPI == 3) {
         // bf16 out, no residual: 32 rows x 128 B per round; 16-B chunk c of row r lives at chunk c ^ (r & 7)
 #pragma unroll
-        for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-            for (int i2 = 0; i2 < 2; ++i2) {
+            for (int r2 = 0; r2 < NI; ++r2) {   // round r2: 16-row blocks 2 r2, 2 r2 + 1 of the wave's 2 NI
 #pragma unroll
                 for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
                     for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
-                            const f32x4 v = pre(acc[mh][nh][i2 * 2 + ii][j], nh, j, mh, i2 * 2 + ii);
+                            const int mh = (2 * r2 + ii) / NI, ib = (2 * r2 + ii) % NI;
+                            const f32x4 v = pre(acc[mh][nh][ib][j], nh, j, mh, ib);
                             u32x2 o;
                             o[0] = pack_bf16x2(v[0], v[1]);
                             o[1] = pack_bf16x2(v[2], v[3]);
@@ -289,7 +289,7 @@ __device__ __forceinline__ void pp_epilogue_impl(const GemmParams& p, f32x4 (&ac
                         const int row = it * 8 + (lane >> 3), ch = lane & 7;
                         o[it] = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((ch ^ (row & 7)) << 4));
                     }
-                    char* rb = reinterpret_cast<char*>(p.C) + ((int64_t)(mw + mh * 64 + i2 * 32) * p.c.ld + nw) * 2;   // wave-uniform
+                    char* rb = reinterpret_cast<char*>(p.C) + ((int64_t)(mw + r2 * 32) * p.c.ld + nw) * 2;   // wave-uniform
                     const uint32_t lo = (uint32_t)(((lane >> 3) * (int)p.c.ld + (lane & 7) * 8) * 2);
 #pragma unroll
                     for (int it = 0; it < 4; ++it)
@@ -299,7 +299,7 @@ __device__ __forceinline__ void pp_epilogue_impl(const GemmParams& p, f32x4 (&ac
                 for (int it = 0; it < 4; ++it) {
                     const int row = it * 8 + (lane >> 3), ch = lane & 7;
                     const u32x4 o = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((ch ^ (row & 7)) << 4));
-                    const int m = mw + mh * 64 + i2 * 32 + row, n = nw + ch * 8;
+                    const int m = mw + r2 * 32 + row, n = nw + ch * 8;
                     // streaming output (qkv, hid, cross K/V: hundreds of MB read once by the next kernel): non-temporal
                     // stores measured -1.5 % step time in situ; the in-place residual stream and the attention
                     // output, which are re-read at once, measured no gain and keep plain stores
@@ -342,8 +342,8 @@ __device__ __forceinline__ void pp_epilogue_impl(const GemmParams& p, f32x4 (&ac
 #pragma unroll
             for (int q = 0; q < PF; ++q) res_load8(q, rr[q]);
 #pragma unroll
-            for (int rnd = 0; rnd < 8; ++rnd) {
-                const int mh = rnd >> 2, i = rnd & 3;
+            for (int rnd = 0; rnd < 2 * NI; ++rnd) {
+                const int mh = rnd / NI, i = rnd % NI;
 #pragma unroll
                 for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
@@ -351,7 +351,7 @@ __device__ __forceinline__ void pp_epilogue_impl(const GemmParams& p, f32x4 (&ac
                         const int ch = nh * 8 + j * 4 + g4;
                         *reinterpret_cast<f32x4*>(stg + r16 * 256 + ((ch ^ r16) << 4)) = pre(acc[mh][nh][i][j], nh, j, mh, i);
                     }
-                if (rnd + PF < 8) res_load8(rnd + PF, rr[(rnd + PF) % (PF + 1)]);
+                if (rnd + PF < 2 * NI) res_load8(rnd + PF, rr[(rnd + PF) % (PF + 1)]);
 #pragma unroll
                 for (int it = 0; it < 2; ++it) {
                     const int row = it * 8 + (lane >> 3), c8 = lane & 7;
@@ -411,8 +411,8 @@ __device__ __forceinline__ void pp_epilogue_impl(const GemmParams& p, f32x4 (&ac
         };
         if (p.res) res_load(0, rcur);
 #pragma unroll
-        for (int rnd = 0; rnd < 8; ++rnd) {
-            const int mh = rnd >> 2, i = rnd & 3;
+        for (int rnd = 0; rnd < 2 * NI; ++rnd) {
+            const int mh = rnd / NI, i = rnd % NI;
 #pragma unroll
             for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
@@ -420,7 +420,7 @@ __device__ __forceinline__ void pp_epilogue_impl(const GemmParams& p, f32x4 (&ac
                     const int ch = nh * 8 + j * 4 + g4;
                     *reinterpret_cast<f32x4*>(stg + r16 * 256 + ((ch ^ r16) << 4)) = pre(acc[mh][nh][i][j], nh, j, mh, i);
                 }
-            if (p.res && rnd < 7) res_load(rnd + 1, rnxt);
+            if (p.res && rnd < 2 * NI - 1) res_load(rnd + 1, rnxt);
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int row = it * 4 + g4, ch = r16;
@@ -447,14 +447,14 @@ __device__ __forceinline__ void pp_epilogue_impl(const GemmParams& p, f32x4 (&ac
 #ifndef HK_EPI_FAST
 #define HK_EPI_FAST 1   // 0: every tile takes the general addressing path (A/B builds)
 #endif
-template <int EPI, int PF_ROUNDS = HK_EPI_PF>
-__device__ __forceinline__ void pp_epilogue(const GemmParams& p, f32x4 (&acc)[2][2][4][2], char* stg, const char* aux,
+template <int EPI, int PF_ROUNDS = HK_EPI_PF, int NI = 4>
+__device__ __forceinline__ void pp_epilogue(const GemmParams& p, f32x4 (&acc)[2][2][NI][2], char* stg, const char* aux,
                                             const int lane, const int wm, const int wn, const int m0, const int n0) {
-    // wave-uniform: whole 128 x 64 sub-tile inside the problem, plain rows for C (and for the in-place residual)
+    // wave-uniform: whole (32 NI) x 64 sub-tile inside the problem, plain rows for C (and for the in-place residual)
     const bool fast = HK_EPI_FAST != 0 && EPI != 1 && p.c.rpb == 0 && (EPI == 0 || EPI == 3 || (p.r.rpb == 0 && p.r.ld == p.c.ld)) &&
-                      m0 + wm * 128 + 128 <= p.M && n0 + wn * 64 + 64 <= p.N;
-    if (fast) pp_epilogue_impl<EPI, PF_ROUNDS, true>(p, acc, stg, aux, lane, wm, wn, m0, n0);
-    else pp_epilogue_impl<EPI, PF_ROUNDS, false>(p, acc, stg, aux, lane, wm, wn, m0, n0);
+                      m0 + wm * (32 * NI) + 32 * NI <= p.M && n0 + wn * 64 + 64 <= p.N;
+    if (fast) pp_epilogue_impl<EPI, PF_ROUNDS, true, NI>(p, acc, stg, aux, lane, wm, wn, m0, n0);
+    else pp_epilogue_impl<EPI, PF_ROUNDS, false, NI>(p, acc, stg, aux, lane, wm, wn, m0, n0);
 }
 
 // ---- per-quadrant epilogue of the 256x256 kernel (HK_EPI_QUAD) ----
@@ -582,11 +582,19 @@ __device__ __forceinline__ void pp_quad_epilogue(const GemmParams& p, f32x4 (&ac
 // registers or exposed latency: at the start of a tile every wave requests the (mean, rstd) pairs of
 // its 128 rows -- 1 KB, one LDS-DMA instruction -- into its idle staging slab; the counted vmcnt of that K-tile's
 // first phase 4 retires it with the operand loads.
-template <int EPI>
+// NI = 3 (round 3): the same kernel on a 192 x 256 tile -- a wave owns 96 x 64 (three 16-row blocks per M-half, 12 MFMAs
+// per phase), the A half-tiles are 96 rows (12 LDS-DMA pieces: waves 4-7 stage the pieces of waves 0-3 a second time as
+// their second piece, same source and destination, so every wave keeps 2 pieces per stage and the counted waits are
+// unchanged; the LDS layout keeps 128-row slots).  For problems whose 256-row tiles make one partial round: 2816 x 4096
+// (prefill o_proj / down_proj) is 176 tiles of 256 rows = 69 % of the CUs for a whole tile time, or 240 tiles of 192 rows
+// for three quarters of it.
+template <int EPI, int NI = 4>
 __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
     constexpr int BK = 64;
-    constexpr int HALF = 128 * BK;  // elements in one half-tile (16 KB)
+    constexpr int HALF = 128 * BK;  // elements in one half-tile slot (16 KB)
     constexpr int BUF = 4 * HALF;   // A-h0, A-h1, W-h0, W-h1
+    constexpr int AH = 32 * NI;     // rows of an A half-tile = rows of a wave's sub-tile
+    constexpr int BM = 2 * AH;      // rows of the output tile
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __bf16* lds = reinterpret_cast<__bf16*>(smem);
@@ -617,13 +625,16 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
         const int lid = c0 + jb + s_tile[kind] * nbx;
         int tm, tn;
         tile_coords(lid, p.nbm, p.nbn, p.gm, tm, tn);
-        const int t0 = (kind < 2 ? tm : tn) * 256;
+        const int t0 = kind < 2 ? tm * BM : tn * 256;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int row = (i * 8 + wave) * 8 + lrow;
+            // piece (8 rows) this wave stages in round i; A pieces past the half-tile's AH rows repeat an earlier wave's
+            int pc = i * 8 + wave;
+            if constexpr (NI != 4) pc = (kind < 2 && pc * 8 >= AH) ? pc - 4 : pc;
+            const int row = pc * 8 + lrow;
             const int sw = (lpc ^ ((row >> 1) & 7)) << 3;
             if (kind < 2) {
-                const int m = min(t0 + kind * 128 + row, p.M - 1);
+                const int m = min(t0 + kind * AH + row, p.M - 1);
                 go[kind][i] = (uint32_t)((p.a.off(m) + sw) * 2);
             } else {
                 const int n = min(t0 + (kind - 2) * 128 + row, p.N - 1);
@@ -637,7 +648,8 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
         // scalar base (operand + K offset) + the piece's 32-bit lane offset: no 64-bit vector address per piece
         const __bf16* kb = (kind < 2 ? p.A : p.W) + s_k[kind] * BK;
         glds16_s(kb, go[kind][0], dst);
-        glds16_s(kb, go[kind][1], dst + 64 * BK);
+        if constexpr (NI == 4) glds16_s(kb, go[kind][1], dst + 64 * BK);
+        else glds16_s(kb, go[kind][1], dst + ((kind < 2 && (8 + wave) * 8 >= AH) ? 32 : 64) * BK);
         s_par[kind] ^= 1;
         if (++s_k[kind] == KT) {
             s_k[kind] = 0;
@@ -660,15 +672,15 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
     const int a_base = wm * HALF;                                        // + mh*64*BK
     const int w_base = (2 + (wn >> 1)) * HALF + (wn & 1) * 64 * BK;      // + nh*32*BK
 
-    f32x4 acc[2][2][4][2];
-    bf16x8 xa[2][4], wb[2][2];
+    f32x4 acc[2][2][NI][2];
+    bf16x8 xa[2][NI], wb[2][2];
     auto zero_acc = [&]() {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < NI; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
@@ -677,12 +689,12 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
 #define HK_ZERO_C 1
 #endif
     constexpr bool ZC_AFTER = HK_ZERO_C != 0 && (EPI == 2 || EPI == 4);   // see the K loop
-    constexpr bool QUAD = HK_EPI_QUAD != 0 && (EPI == 0 || EPI == 3);     // quadrant epilogues inside the last K-tile
+    constexpr bool QUAD = HK_EPI_QUAD != 0 && (EPI == 0 || EPI == 3) && NI == 4;   // quadrant epilogues inside the last K-tile
 
     auto load_a = [&](int buf, int mh) {
-        const __bf16* s0 = lds + buf * BUF + a_base + mh * 64 * BK;
+        const __bf16* s0 = lds + buf * BUF + a_base + mh * (16 * NI) * BK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
             xa[0][i] = *reinterpret_cast<const bf16x8*>(s0 + i * 16 * BK + foff0);
             xa[1][i] = *reinterpret_cast<const bf16x8*>(s0 + i * 16 * BK + foff1);
         }
@@ -707,7 +719,7 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
         __builtin_amdgcn_s_setprio(1);                                                                      \
-        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int i = 0; i < 4; ++i)      \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int i = 0; i < NI; ++i)     \
             _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[MH][NH][i][j] =                               \
                 __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[kk][j], xa[kk][i],                               \
                     (FIRST && kk == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[MH][NH][i][j], 0, 0, 0);           \
@@ -717,7 +729,7 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
     } while (0)
 
     char* stg = smem + 2 * BUF * 2 + wave * 4096;
-    auto epilogue = [&](int m0, int n0) __attribute__((always_inline)) { pp_epilogue<EPI>(p, acc, stg, stg, lane, wm, wn, m0, n0); };
+    auto epilogue = [&](int m0, int n0) __attribute__((always_inline)) { pp_epilogue<EPI, HK_EPI_PF, NI>(p, acc, stg, stg, lane, wm, wn, m0, n0); };
 
     // (Measured and not kept: starting eight classes of workgroups a fraction of a tile time apart (s_sleep), so that
     // a CU's epilogue stores would meet the others' main loops instead of 255 other store bursts: every launch got slower
@@ -762,7 +774,9 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
             // load of this tile, so the first counted vmcnt retires it.
             int tm_, tn_;
             tile_coords(c0 + jb + ti * nbx, p.nbm, p.nbn, p.gm, tm_, tn_);
-            glds16_v(p.row_stats + 2 * ((int64_t)tm_ * 256 + wm * 128 + 2 * lane), stg);
+            // (128 rows from the wave's first; the statistics array is padded to a multiple of 256 rows: clamp for BM = 192)
+            if constexpr (NI == 4) glds16_v(p.row_stats + 2 * ((int64_t)tm_ * 256 + wm * 128 + 2 * lane), stg);
+            else glds16_v(p.row_stats + 2 * (int64_t)min(tm_ * BM + wm * AH + 2 * lane, (p.M + 255) / 256 * 256 - 2), stg);
         }
         auto ktile = [&](auto first_) __attribute__((always_inline)) {
             constexpr bool FIRST = decltype(first_)::value;
@@ -800,7 +814,7 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
             // wave-uniform: the wave's whole sub-tile inside the problem and plain C rows -> its quadrants leave during the
             // last K-tile; otherwise the ordinary epilogue after it.  Both forms pass the same barriers.
             // (two K-tiles at least: the tile's epilogue operands are retired by the first K-tile's counted wait)
-            const bool fastq = KT >= 2 && p.c.rpb == 0 && tm * 256 + wm * 128 + 128 <= p.M && tn * 256 + wn * 64 + 64 <= p.N && HK_DBG(p) == 0;
+            const bool fastq = KT >= 2 && p.c.rpb == 0 && tm * BM + wm * AH + AH <= p.M && tn * 256 + wn * 64 + 64 <= p.N && HK_DBG(p) == 0;
             const int kt_main = fastq ? KT - 1 : KT;
             for (int t = 0; t < kt_main; ++t) ktile(std::false_type{});
             if (fastq) {
@@ -834,7 +848,7 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
                 // q(1,0): in front of the next tile's first read section (the partner group is one barrier behind / ahead)
                 pp_quad_epilogue<EPI, 1, 0>(p, acc, stg, lane, wm, wn, m0, n0);
             } else {
-                pp_epilogue_impl<EPI, HK_EPI_PF, false>(p, acc, stg, stg, lane, wm, wn, tm * 256, tn * 256);
+                pp_epilogue_impl<EPI, HK_EPI_PF, false, NI>(p, acc, stg, stg, lane, wm, wn, tm * BM, tn * 256);
                 zero_acc();
             }
         } else {
@@ -845,7 +859,7 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
             for (int t = 0; t < KT; ++t) ktile(std::false_type{});
         }
         if (trc && tid == 0 && ti < 31) trc[2 + 2 * ti] = __builtin_amdgcn_s_memrealtime();
-        epilogue(tm * 256, tn * 256);
+        epilogue(tm * BM, tn * 256);
         if (trc && tid == 0 && ti < 31) trc[3 + 2 * ti] = __builtin_amdgcn_s_memrealtime();
         if constexpr (!ZC_AFTER) zero_acc();
         }
@@ -1268,12 +1282,12 @@ int launch(const GemmParams& p, hipStream_t stream) {
     return HK_OK;
 }
 
-template <int EPI>
+template <int EPI, int NI = 4>
 int launch_pp(const GemmParams& p, hipStream_t stream) {
     constexpr int LDS = 2 * 4 * 128 * 64 * 2 + 8 * 4096;  // operand buffers + epilogue staging = 160 KB
     static std::atomic<unsigned long long> attr_done{0};   // per device
     {
-        const hipError_t e = hk_lds_attr_once(attr_done, reinterpret_cast<const void*>(&hk_gemm_pp_kernel<EPI>), LDS);
+        const hipError_t e = hk_lds_attr_once(attr_done, reinterpret_cast<const void*>(&hk_gemm_pp_kernel<EPI, NI>), LDS);
         if (e != hipSuccess) {
             hk_set_error("hk_gemm_bf16: hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e));
             return HK_ELAUNCH;
@@ -1292,7 +1306,7 @@ int launch_pp(const GemmParams& p, hipStream_t stream) {
         ncu = n;
     }
     GemmParams q = p;
-    q.nbm = (p.M + 255) / 256;
+    q.nbm = (p.M + 64 * NI - 1) / (64 * NI);
     q.nbn = (p.N + 255) / 256;
     const int ntiles = q.nbm * q.nbn;
     // HK_GEMM_VARIANT=2: one tile per workgroup (grid = tiles) instead of the persistent walk
@@ -1309,7 +1323,7 @@ int launch_pp(const GemmParams& p, hipStream_t stream) {
         q.trace = grid <= 16384 ? trace_buf : nullptr;
     }
 #endif
-    hipLaunchKernelGGL(hk_gemm_pp_kernel<EPI>, dim3(grid), dim3(512), LDS, stream, q);
+    hipLaunchKernelGGL((hk_gemm_pp_kernel<EPI, NI>), dim3(grid), dim3(512), LDS, stream, q);
     HK_CHECK_LAUNCH("hk_gemm_bf16");
 #ifdef HK_DIAG
     if (trace_path && q.trace) {
@@ -1554,6 +1568,14 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
             tail.m_off = whole;
             tail.M = d->M - whole;
             p.M = whole;
+        }
+        // One partial round of 256-row tiles (tiles256 < CUs) that 192-row tiles still cover in one round: the round then
+        // takes 3/4 of the time on more of the chip (prefill o_proj / down_proj at M = 2816: 176 -> 240 workgroups).
+        // HK_GEMM_192=0 turns the rule off (A/B aid).  Instantiated for the epilogue kinds that meet such shapes.
+        static const int r192 = getenv("HK_GEMM_192") ? atoi(getenv("HK_GEMM_192")) : 1;
+        const long tiles192 = (long)((d->M + 191) / 192) * nbn;
+        if (r192 != 0 && tail.M == 0 && !use_duo && tiles256 < ncu && tiles192 <= ncu && tiles192 > tiles256 && (epi == 0 || epi == 1)) {
+            return epi == 0 ? launch_pp<0, 3>(p, s) : launch_pp<1, 3>(p, s);
         }
         int rc;
         if (epi == 3) rc = use_duo ? launch_duo<3>(p, s) : launch_pp<3>(p, s);

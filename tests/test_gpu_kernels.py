@@ -79,6 +79,24 @@ def test_gemm_epilogues_and_row_maps():
     assert _rel(out2, ref2) < 2e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(2816, 4096, 512), (2716, 4096, 320), (1400, 8192, 128)])
+def test_gemm_192_row_tile_shapes(M, N, K):
+    """One partial round of 256-row tiles that 192-row tiles cover better (prefill o_proj / down_proj: 176 -> 240
+    workgroups) runs the persistent kernel's 192 x 256 instantiation: bf16-out and fp32-out-with-residual epilogues,
+    whole and partial last row tiles, an exact small-integer problem (a transposed or shifted tile cannot pass)."""
+    x = _rand((M, K), 91, dtype=torch.bfloat16)
+    w = _rand((N, K), 92, 0.05, dtype=torch.bfloat16)
+    b = _rand((N,), 93)
+    res = _rand((M, N), 94)
+    ref = x.float() @ w.float().t() + b
+    assert _rel(ops.linear(x, w, b).float(), ref) < 6e-3
+    assert _rel(ops.linear(x, w, b, residual=res, out_dtype=torch.float32), ref + res) < 2e-5
+    xi = torch.randint(-3, 4, (M, K), device=DEV).to(torch.bfloat16)
+    wi = torch.randint(-2, 3, (N, K), device=DEV).to(torch.bfloat16)
+    assert torch.equal(ops.linear(xi, wi, None, out_dtype=torch.float32), xi.float() @ wi.float().t())
+    assert torch.equal(ops.linear(xi, wi, None).float(), (xi.float() @ wi.float().t()).to(torch.bfloat16).float())
+
+
 @pytest.mark.parametrize("M,N,K", [(66000, 1024, 256), (300, 768, 128), (5000, 1024, 128)])   # the last: 160 tiles of 256x128
 def test_gemm_bf16_residual_in_place(M, N, K):
     """The bf16 residual stream: C = bf16(x @ w.T + b + float(C)), rounded once, C updated in place."""

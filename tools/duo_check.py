@@ -79,7 +79,8 @@ def digest():
     lib.hk_gemm_duo_mask(0)
     for kind in (0, 3, 2, 4, 1):
         for (M, N, K) in ((25088, 1024 if kind in (2, 4) else 3072, 1024), (25088 + 77, 1024, 4096 if kind != 3 else 1024),
-                          (16384, 4096 if kind in (0, 3) else 1024, 1024), (32768 + 256, 1024, 768), (512, 4096, 64), (1024, 2048, 128)):
+                          (16384, 4096 if kind in (0, 3) else 1024, 1024), (32768 + 256, 1024, 768), (512, 4096, 64), (1024, 2048, 128),
+                          (2816, 4096, 1024), (2716, 4096, 512)):    # one partial round of 256-row tiles: the 192-row tile's shapes
             args = make(M, N, K, kind)
             out = args[-1].clone()
             rp = args[6].clone() if args[6] is not None else None
@@ -118,6 +119,19 @@ def time_pp(M=100352):
         del args, out
 
 
+def time_llm(M=2816):
+    """Prefill GEMM shapes at B = 8, S = 352 (Vicuna-7B): for A/B of dispatch rules through the environment."""
+    shapes = (("qkv", 0, 12288, 4096), ("o_proj", 1, 4096, 4096), ("gate_up", 0, 22016, 4096), ("down_proj", 1, 4096, 11008))
+    lib.hk_gemm_duo_mask(0)
+    tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("HK_GEMM"))
+    for name, kind, N, K in shapes:
+        args = make(M, N, K, kind)
+        out = args[-1]
+        t = min(timeit(lambda: run(kind, *args[:7], out), iters=16) for _ in range(3))
+        print(f"[{tag}] {name:10s} M={M} N={N} K={K}: {t:8.1f} us  {2.0 * M * N * K / t / 1e6:7.1f} TFLOP/s", flush=True)
+        del args, out
+
+
 def time_all(M=100352):
     shapes = (("qkv (fold)", 3, 3072, 1024), ("fc1+gelu (fold)", 3, 4096, 1024), ("proj (row_part)", 4, 1024, 1024),
               ("fc2 (row_part)", 4, 1024, 4096), ("ckv", 0, 9216, 1024), ("patch", 2, 1024, 768))
@@ -145,6 +159,8 @@ if __name__ == "__main__":
             sys.exit(1)
     if "time" in what:
         time_all()
+    if "llm" in what:
+        time_llm()
     if "digest" in what:
         digest()
     if "pp" in what:
