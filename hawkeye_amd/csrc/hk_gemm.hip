@@ -1527,6 +1527,12 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
     // on: B = 2 T = 16 10.58 -> 9.48 ms, B = 4 T = 8 9.43 -> 8.35, B = 3 T = 12 10.05 -> 9.01; lower bound 160 -> 144: B = 2 T = 12
     // 8.14 -> 7.55, B = 1 T = 7 4.53 -> 4.30.  Two or three rounds of these tiles for the N = 1024 layers (257-768 tiles, in place
     // of a persistent round plus its tail) lose: B = 4 T = 12 11.47 -> 12.2 ms, B = 6 T = 12 14.86 -> 15.9, B = 8 T = 12 20.3 -> 20.95.
+    static const int r192 = getenv("HK_GEMM_192") ? atoi(getenv("HK_GEMM_192")) : 1;
+    const long tiles192 = (long)((d->M + 191) / 192) * ((d->N + 255) / 256);
+    const int epi = p.row_stats ? 3 : (!p.out_f32 && !p.res) ? 0 : (!p.out_f32 && p.res_bf16) ? (p.row_part ? 4 : 2) : 1;
+    // HK_GEMM_192=2 (experiments): the 192-row tile for every launch it covers in one round, before the other small-shape rules
+    if (r192 == 2 && variant != 0 && d->N % 256 == 0 && off32 && tiles192 <= 256 && (epi == 0 || epi == 1))
+        return epi == 0 ? launch_pp<0, 3>(p, s) : launch_pp<1, 3>(p, s);
     if (mid_window(d->M)) return small(p);
     if (variant != 0 && tiles256 >= pp_min && d->N % 256 == 0 && off32) {
         // Tail balance: the persistent kernel gives each of the 256 CUs floor or ceil(tiles / 256) tiles, so a
@@ -1559,7 +1565,6 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
         // HK_GEMM_DUO: bit e set = epilogue kind e runs on the two-workgroups-per-CU 256x128 kernel (hk_gemm_duo_kernel)
         // instead of the 256x256 one (A/B switch; the default is what measured faster per epilogue kind)
         const int duo = duo_mask().load(std::memory_order_relaxed);
-        const int epi = p.row_stats ? 3 : (!p.out_f32 && !p.res) ? 0 : (!p.out_f32 && p.res_bf16) ? (p.row_part ? 4 : 2) : 1;
         const bool use_duo = ((duo >> epi) & 1) != 0 && p.K >= 128 && d->N % 128 == 0 && d->a_rows.rows_per_batch == 0 &&
                              p.M >= 256;
         if (use_duo && p.M % 256 != 0) {
@@ -1572,8 +1577,6 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
         // One partial round of 256-row tiles (tiles256 < CUs) that 192-row tiles still cover in one round: the round then
         // takes 3/4 of the time on more of the chip (prefill o_proj / down_proj at M = 2816: 176 -> 240 workgroups).
         // HK_GEMM_192=0 turns the rule off (A/B aid).  Instantiated for the epilogue kinds that meet such shapes.
-        static const int r192 = getenv("HK_GEMM_192") ? atoi(getenv("HK_GEMM_192")) : 1;
-        const long tiles192 = (long)((d->M + 191) / 192) * nbn;
         if (r192 != 0 && tail.M == 0 && !use_duo && tiles256 < ncu && tiles192 <= ncu && tiles192 > tiles256 && (epi == 0 || epi == 1)) {
             return epi == 0 ? launch_pp<0, 3>(p, s) : launch_pp<1, 3>(p, s);
         }
