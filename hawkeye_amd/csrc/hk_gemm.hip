@@ -142,6 +142,13 @@ __device__ __forceinline__ f32x4 load_res4(const GemmParams& p, int64_t off) {
     return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + off);
 }
 
+// SwiGLU on interleaved columns (HK_ACT_SWIGLU): a lane's 4 consecutive columns are (gate, up, gate, up) of two output
+// columns; silu(g) * u with silu(g) = g / (1 + 2^(-g log2 e)) (g -> -inf: 2^(..) = inf, 1 / inf = 0, g * 0 = -0).
+__device__ __forceinline__ float silu_mul(const float g, const float u) {
+    const float e = __builtin_amdgcn_exp2f(g * -1.4426950408889634f);
+    return g * __builtin_amdgcn_rcpf(1.0f + e) * u;
+}
+
 // One lane's 4 consecutive output columns of one row: bias, column scale, activation, residual, store.
 __device__ __forceinline__ f32x4 epi_store(const GemmParams& p, f32x4 v, const f32x4 bias, const f32x4 cc, const f32x4 res,
                                            int n, int64_t coff, float rs, float rm) {
@@ -152,6 +159,10 @@ __device__ __forceinline__ f32x4 epi_store(const GemmParams& p, f32x4 v, const f
         v += bias;
     }
     if (p.scale_cols != 0 && n < p.scale_cols) v *= p.scale;
+    if (p.act == HK_ACT_SWIGLU) {   // bf16 out, no residual (checked on the host): two output columns at n / 2
+        *reinterpret_cast<uint32_t*>(reinterpret_cast<__bf16*>(p.C) + coff + (n >> 1)) = pack_bf16x2(silu_mul(v[0], v[1]), silu_mul(v[2], v[3]));
+        return v;
+    }
     if (p.act == HK_ACT_GELU_ERF) v = p.out_f32 ? gelu_erf4(v) : gelu_erf4_bf16dst(v);
     if (p.res) v += res;
     if (p.out_f32) {
@@ -263,6 +274,42 @@ __device__ __forceinline__ void pp_epilogue_impl(const GemmParams& p, f32x4 (&ac
     const int mw = m0 + wm * (32 * NI);  // first row / column of this wave's sub-tile
     const int nw = n0 + wn * 64;
     const int r16 = lane & 15, g4 = lane >> 4;
+    if (EPI == 5) {
+        // SwiGLU on interleaved (gate, up) columns: the wave's 64 columns become 32 output columns, 64 B per row.  32 rows per
+        // round through the slab: a lane's two results are 4 bytes of 16-byte chunk nh*2 + j of its row (the four lanes
+        // g4 = 0..3 fill the chunk); chunk c of row r lives at c ^ ((r >> 2) & 3), which spreads the 16 rows x 16 B of one
+        // ds_write_b32 over all banks; read back as whole 64-byte row segments, 16 rows per store instruction.
+        const int on = nw >> 1;   // first output column of the wave
+#pragma unroll
+        for (int r2 = 0; r2 < NI; ++r2) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int mh = (2 * r2 + ii) / NI, ib = (2 * r2 + ii) % NI;
+                        const f32x4 v = acc[mh][nh][ib][j] + bias[nh][j];
+                        const int row = ii * 16 + r16;
+                        const int ch = nh * 2 + j;
+                        *reinterpret_cast<uint32_t*>(stg + row * 64 + ((ch ^ ((row >> 2) & 3)) << 4) + g4 * 4) =
+                            pack_bf16x2(silu_mul(v[0], v[1]), silu_mul(v[2], v[3]));
+                    }
+            u32x4 o[2];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int row = it * 16 + (lane >> 2), c = lane & 3;
+                o[it] = *reinterpret_cast<const u32x4*>(stg + row * 64 + ((c ^ ((row >> 2) & 3)) << 4));
+            }
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int m = mw + r2 * 32 + it * 16 + (lane >> 2), n = nw + (lane & 3) * 16;   // n: first W row of the lane's 8 outputs
+                if (m < p.M && n < p.N)
+                    __builtin_nontemporal_store(o[it], reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(p.C) + p.c.off(m) + on + (lane & 3) * 8));
+            }
+        }
+        return;
+    }
     if (EPI == 0 || EPI == 3) {
         // bf16 out, no residual: 32 rows x 128 B per round; 16-B chunk c of row r lives at chunk c ^ (r & 7)
 #pragma unroll
@@ -451,7 +498,7 @@ template <int EPI, int PF_ROUNDS = HK_EPI_PF, int NI = 4>
 __device__ __forceinline__ void pp_epilogue(const GemmParams& p, f32x4 (&acc)[2][2][NI][2], char* stg, const char* aux,
                                             const int lane, const int wm, const int wn, const int m0, const int n0) {
     // wave-uniform: whole (32 NI) x 64 sub-tile inside the problem, plain rows for C (and for the in-place residual)
-    const bool fast = HK_EPI_FAST != 0 && EPI != 1 && p.c.rpb == 0 && (EPI == 0 || EPI == 3 || (p.r.rpb == 0 && p.r.ld == p.c.ld)) &&
+    const bool fast = HK_EPI_FAST != 0 && EPI != 1 && EPI != 5 && p.c.rpb == 0 && (EPI == 0 || EPI == 3 || (p.r.rpb == 0 && p.r.ld == p.c.ld)) &&
                       m0 + wm * (32 * NI) + 32 * NI <= p.M && n0 + wn * 64 + 64 <= p.N;
     if (fast) pp_epilogue_impl<EPI, PF_ROUNDS, true, NI>(p, acc, stg, aux, lane, wm, wn, m0, n0);
     else pp_epilogue_impl<EPI, PF_ROUNDS, false, NI>(p, acc, stg, aux, lane, wm, wn, m0, n0);
@@ -576,7 +623,7 @@ __device__ __forceinline__ void pp_quad_epilogue(const GemmParams& p, f32x4 (&ac
 // operand buffers (128 KB + 8 x 4 KB = all 160 KB of the CU) and writes whole row segments.
 // EPI selects the one epilogue this instantiation carries: 0 = bf16 out, no residual; 1 = fp32 staging
 // (fp32 out and/or fp32 residual); 2 = bf16 residual stream updated in place (4 = 2 that also emits the row sums
-// the next LayerNorm needs, row_part); 3 = 0 with the LayerNorm of A folded
+// the next LayerNorm needs, row_part); 5 = bf16 out with SwiGLU on interleaved (gate, up) columns; 3 = 0 with the LayerNorm of A folded
 // in (row_stats / col_c).  The folded form is its own instantiation because its extra live values cost the main loop
 // of EPI 0 ~20 % when they share one body (measured in situ), and its row statistics reach the epilogue without
 // registers or exposed latency: at the start of a tile every wave requests the (mean, rstd) pairs of
@@ -1396,7 +1443,12 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
                    d->r_rows.batch_stride % 4 == 0,
                "hk_gemm_bf16: C/residual leading dimensions must be multiples of 4 elements");
     HK_REQUIRE(d->a_rows.ld >= d->K && d->ldw >= d->K, "hk_gemm_bf16: lda/ldw smaller than K");
-    HK_REQUIRE(d->act == HK_ACT_NONE || d->act == HK_ACT_GELU_ERF, "hk_gemm_bf16: unknown act %d", d->act);
+    HK_REQUIRE(d->act == HK_ACT_NONE || d->act == HK_ACT_GELU_ERF || d->act == HK_ACT_SWIGLU, "hk_gemm_bf16: unknown act %d", d->act);
+    HK_REQUIRE(d->act != HK_ACT_SWIGLU || (d->out_dtype == HK_DT_BF16 && d->residual == nullptr && d->row_stats == nullptr &&
+                                           d->row_part == nullptr && d->scale_cols == 0 && d->split_k <= 1 && d->N % 32 == 0 &&
+                                           (uintptr_t)d->C % 16 == 0),
+               "hk_gemm_bf16: HK_ACT_SWIGLU needs bf16 output [M, N / 2], N %% 32 == 0, no residual / folded LayerNorm / row_part / "
+               "column scale / split_k");
     HK_REQUIRE(d->out_dtype == HK_DT_BF16 || d->out_dtype == HK_DT_F32, "hk_gemm_bf16: unknown out_dtype %d",
                d->out_dtype);
     HK_REQUIRE(d->scale_cols % 4 == 0, "hk_gemm_bf16: scale_cols must be a multiple of 4");
@@ -1529,7 +1581,7 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
     // of a persistent round plus its tail) lose: B = 4 T = 12 11.47 -> 12.2 ms, B = 6 T = 12 14.86 -> 15.9, B = 8 T = 12 20.3 -> 20.95.
     static const int r192 = getenv("HK_GEMM_192") ? atoi(getenv("HK_GEMM_192")) : 1;
     const long tiles192 = (long)((d->M + 191) / 192) * ((d->N + 255) / 256);
-    const int epi = p.row_stats ? 3 : (!p.out_f32 && !p.res) ? 0 : (!p.out_f32 && p.res_bf16) ? (p.row_part ? 4 : 2) : 1;
+    const int epi = p.act == HK_ACT_SWIGLU ? 5 : p.row_stats ? 3 : (!p.out_f32 && !p.res) ? 0 : (!p.out_f32 && p.res_bf16) ? (p.row_part ? 4 : 2) : 1;
     // HK_GEMM_192=2 (experiments): the 192-row tile for every launch it covers in one round, before the other small-shape rules
     if (r192 == 2 && variant != 0 && d->N % 256 == 0 && off32 && tiles192 <= 256 && (epi == 0 || epi == 1))
         return epi == 0 ? launch_pp<0, 3>(p, s) : launch_pp<1, 3>(p, s);
@@ -1565,7 +1617,7 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
         // HK_GEMM_DUO: bit e set = epilogue kind e runs on the two-workgroups-per-CU 256x128 kernel (hk_gemm_duo_kernel)
         // instead of the 256x256 one (A/B switch; the default is what measured faster per epilogue kind)
         const int duo = duo_mask().load(std::memory_order_relaxed);
-        const bool use_duo = ((duo >> epi) & 1) != 0 && p.K >= 128 && d->N % 128 == 0 && d->a_rows.rows_per_batch == 0 &&
+        const bool use_duo = epi != 5 && ((duo >> epi) & 1) != 0 && p.K >= 128 && d->N % 128 == 0 && d->a_rows.rows_per_batch == 0 &&
                              p.M >= 256;
         if (use_duo && p.M % 256 != 0) {
             // the duo kernel addresses whole 256-row tiles through scalar bases: leftover rows join (or become) the tail launch
@@ -1585,6 +1637,7 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
         else if (epi == 0) rc = use_duo ? launch_duo<0>(p, s) : launch_pp<0>(p, s);
         else if (epi == 4) rc = use_duo ? launch_duo<4>(p, s) : launch_pp<4>(p, s);
         else if (epi == 2) rc = use_duo ? launch_duo<2>(p, s) : launch_pp<2>(p, s);
+        else if (epi == 5) rc = launch_pp<5>(p, s);
         else rc = use_duo ? launch_duo<1>(p, s) : launch_pp<1>(p, s);
         if (rc != HK_OK || tail.M == 0) return rc;
         return small(tail);

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # HK_LIB_PATH: development aid (tools/ab_lib.py times two builds of the library on the same device); never a fallback
 LIB_PATH = os.environ.get("HK_LIB_PATH") or os.path.join(_HERE, "libhawkeye_hip.so")
 
-HK_ACT_NONE, HK_ACT_GELU_ERF = 0, 1
+HK_ACT_NONE, HK_ACT_GELU_ERF, HK_ACT_SWIGLU = 0, 1, 2
 HK_DT_BF16, HK_DT_F32 = 0, 1
 
 

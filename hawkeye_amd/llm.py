@@ -13,6 +13,7 @@ alpha=32 on q_proj / v_proj) are merged into the dense weights at load: W + (alp
 There is no CPU path: everything below enqueues C-ABI calls of libhawkeye_hip.so (include/hawkeye_hip.h).
 """
 import ctypes as C
+import os
 from collections import OrderedDict
 from typing import Dict, List, Optional, Tuple
 
@@ -77,6 +78,10 @@ class LlamaPrefill:
             raise RuntimeError("hidden_size must be a multiple of 256 and intermediate_size of 64")
         self.lib = L.load()
         self.w: Dict[str, torch.Tensor] = {}
+        # gate | up projections with silu(gate) * up in the GEMM epilogue (HK_ACT_SWIGLU, interleaved weight rows) instead of
+        # a [M, 2I] matrix and an elementwise pass over it.  HK_LLM_SWIGLU=0: the two-launch form (A/B aid); read at
+        # construction because it decides the packed weight layout.
+        self.fused_swiglu = os.environ.get("HK_LLM_SWIGLU", "1") != "0"
         # Prompt length differs per example, so an eval run meets a new (B, S) on almost every call.  Workspace tensors
         # are views of ONE pool of grow-only buffers (the engine's _Pool): the memory held is the largest size each
         # buffer was ever asked for (qkv alone is 2.2 GB at B = 8, S = 352), not the sum over shapes; plans are host-side
@@ -123,8 +128,10 @@ class LlamaPrefill:
                 p, o = f"model.layers.{i}.", f"l{i}."
                 w[o + "qkv"] = bf(torch.cat([sd[p + f"self_attn.{n}_proj.weight"].detach().float() for n in "qkv"]))
                 w[o + "o"] = bf(sd[p + "self_attn.o_proj.weight"])
-                w[o + "gu"] = bf(torch.cat([sd[p + "mlp.gate_proj.weight"].detach().float(),
-                                            sd[p + "mlp.up_proj.weight"].detach().float()]))
+                gate, up = sd[p + "mlp.gate_proj.weight"].detach().float(), sd[p + "mlp.up_proj.weight"].detach().float()
+                # fused SwiGLU epilogue (HK_ACT_SWIGLU): rows interleaved (gate_0, up_0, gate_1, up_1, ...); else gate | up
+                w[o + "gu"] = bf(torch.stack([gate, up], 1).reshape(2 * gate.shape[0], gate.shape[1]) if self.fused_swiglu
+                                 else torch.cat([gate, up]))
                 w[o + "down"] = bf(sd[p + "mlp.down_proj.weight"])
                 w[o + "n1"], w[o + "n2"] = f32(sd[p + "input_layernorm.weight"]), f32(sd[p + "post_attention_layernorm.weight"])
             w["norm"] = f32(sd["model.norm.weight"])
@@ -187,7 +194,7 @@ class LlamaPrefill:
             ws["xn"] = buf("xn", (M, D), bf16)
             ws["qkv"] = buf("qkv", (Lyr, M, 3 * D), bf16)  # per layer: q | k | v; k, v = the KV cache
             ws["att"] = buf("att", (M, D), bf16)
-            ws["gu"] = buf("gu", (M, 2 * I), bf16)
+            ws["gu"] = None if self.fused_swiglu else buf("gu", (M, 2 * I), bf16)
             ws["act"] = buf("act", (M, I), bf16)
             ws["last"] = buf("last", (B,), torch.int64)
             ws["pos"] = buf("pos", (M,), torch.int32) if with_pos else None
@@ -214,8 +221,15 @@ class LlamaPrefill:
             self._gemm(plan, P(att), w[o + "o"], P(x), M, D, D, residual=P(x), r_rows=(D, 0, 0), out_f32=True)
             plan.steps.append((self.lib.hk_rmsnorm, (P(x), L.HK_DT_F32, P(w[o + "n2"]), P(xn), M, D, cfg.rms_norm_eps),
                                "hk_rmsnorm"))
-            self._gemm(plan, P(xn), w[o + "gu"], P(gu), M, 2 * I, D)
-            plan.steps.append((self.lib.hk_silu_mul_bf16, (P(gu), P(act), M, I), "hk_silu_mul_bf16"))
+            if self.fused_swiglu:
+                # gate | up projections and silu(gate) * up in one launch: the [M, 2I] matrix is never written
+                d = ops.gemm_desc(P(xn), w[o + "gu"].data_ptr(), P(act), M, 2 * I, D, a_rows=(D, 0, 0), c_rows=(I, 0, 0),
+                                  act=L.HK_ACT_SWIGLU)
+                plan.keep.append(d)
+                plan.steps.append((self.lib.hk_gemm_bf16, (C.byref(d),), "hk_gemm_bf16"))
+            else:
+                self._gemm(plan, P(xn), w[o + "gu"], P(gu), M, 2 * I, D)
+                plan.steps.append((self.lib.hk_silu_mul_bf16, (P(gu), P(act), M, I), "hk_silu_mul_bf16"))
             self._gemm(plan, P(act), w[o + "down"], P(x), M, D, I, residual=P(x), r_rows=(D, 0, 0), out_f32=True)
         plan.steps.append((self.lib.hk_rmsnorm, (P(x), L.HK_DT_F32, P(w["norm"]), P(xn), M, D, cfg.rms_norm_eps), "hk_rmsnorm"))
         # last valid position of every row -> lm_head (LlamaForCausalLM.forward :688-700; generation reads logits[:, -1])

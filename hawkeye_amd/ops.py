@@ -76,13 +76,21 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
             raise RuntimeError("linear: residual must be an fp32 or bf16 GPU tensor")
         if residual.shape != (M, N) or residual.stride(1) != 1:
             raise RuntimeError("linear: residual must be [M,N] row-major")
+    if act == "swiglu":   # w rows interleaved (gate_0, up_0, gate_1, up_1, ...): out [M, N / 2] = silu(gate) * up
+        if residual is not None or out_dtype != torch.bfloat16 or N % 32 != 0 or scale_cols != 0:
+            raise RuntimeError("linear: act='swiglu' needs bf16 output, N % 32 == 0, no residual, no column scale")
+    elif act not in ("none", "gelu"):
+        raise RuntimeError(f"linear: unknown act {act!r}")
+    NO = N // 2 if act == "swiglu" else N
     if out is None:
-        out = torch.empty((M, N), dtype=out_dtype, device=x.device)
+        out = torch.empty((M, NO), dtype=out_dtype, device=x.device)
+    if tuple(out.shape) != (M, NO) or out.stride(1) != 1:
+        raise RuntimeError(f"linear: out must be [{M}, {NO}] row-major")
     _need(out, out_dtype, "out")
     d = gemm_desc(x.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, K, bias=_ptr(bias), residual=_ptr(residual),
                   a_rows=(x.stride(0), 0, 0), c_rows=(out.stride(0), 0, 0),
                   r_rows=(residual.stride(0), 0, 0) if residual is not None else (0, 0, 0), ldw=w.stride(0),
-                  act=L.HK_ACT_GELU_ERF if act == "gelu" else L.HK_ACT_NONE, out_f32=out_dtype == torch.float32,
+                  act={"gelu": L.HK_ACT_GELU_ERF, "swiglu": L.HK_ACT_SWIGLU}.get(act, L.HK_ACT_NONE), out_f32=out_dtype == torch.float32,
                   res_bf16=residual is not None and residual.dtype == torch.bfloat16,
                   scale_cols=scale_cols, scale=scale)
     if row_stats is not None:

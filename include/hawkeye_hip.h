@@ -28,6 +28,11 @@ extern "C" {
 
 #define HK_ACT_NONE 0
 #define HK_ACT_GELU_ERF 1
+/* SwiGLU on interleaved columns (row f1, modeling_llama.py:143-155 `down_proj(act_fn(gate_proj(x)) * up_proj(x))`): W holds the rows of
+ * gate_proj and up_proj interleaved (gate_0, up_0, gate_1, up_1, ...), N counts the rows of W, and C is bf16 [M, N / 2] with
+ * C[m, k] = silu(y[m, 2k]) * y[m, 2k + 1], y = A . W^T + bias -- the [M, N] gate|up matrix is never written.  Needs
+ * N % 32 == 0, bf16 output, no residual / folded LayerNorm / row_part / column scale / split_k; c_rows addresses the N / 2-column output. */
+#define HK_ACT_SWIGLU 2
 
 #define HK_DT_BF16 0
 #define HK_DT_F32 1

@@ -97,6 +97,31 @@ def test_gemm_192_row_tile_shapes(M, N, K):
     assert torch.equal(ops.linear(xi, wi, None).float(), (xi.float() @ wi.float().t()).to(torch.bfloat16).float())
 
 
+@pytest.mark.parametrize("M,N,K,bias", [(1280, 8192, 256, False), (1300, 8192, 128, True), (100, 512, 64, True),
+                                        (2816, 22016, 128, False), (257, 1056, 192, False), (66000, 512, 64, True)])
+def test_gemm_swiglu_epilogue_on_interleaved_gate_up_rows(M, N, K, bias):
+    """HK_ACT_SWIGLU (modeling_llama.py:143-155): W rows interleaved (gate_0, up_0, ...), C [M, N/2] = silu(gate) * up, on the
+    persistent kernel (whole and partial tiles, with and without its tail launch) and on the multi-stage kernel; vs fp32."""
+    x = _rand((M, K), 71, dtype=torch.bfloat16)
+    I = N // 2
+    gate = _rand((I, K), 72, 0.08, dtype=torch.bfloat16)
+    up = _rand((I, K), 73, 0.08, dtype=torch.bfloat16)
+    b = _rand((N,), 74) if bias else None
+    w = torch.stack([gate, up], 1).reshape(N, K).contiguous()
+    out = ops.linear(x, w, b, act="swiglu")
+    assert out.shape == (M, I)
+    g = x.float() @ gate.float().t()
+    u = x.float() @ up.float().t()
+    if bias:
+        g, u = g + b[0::2], u + b[1::2]
+    ref = torch.nn.functional.silu(g) * u
+    assert _rel(out.float(), ref) < 6e-3          # bf16 output rounding
+    # a strided output (the caller's [M, I] view of a wider buffer)
+    wide = torch.zeros((M, I + 64), dtype=torch.bfloat16, device=DEV)
+    ops.linear(x, w, b, act="swiglu", out=wide[:, :I])
+    assert torch.equal(wide[:, :I], out) and not wide[:, I:].any()
+
+
 @pytest.mark.parametrize("M,N,K", [(66000, 1024, 256), (300, 768, 128), (5000, 1024, 128)])   # the last: 160 tiles of 256x128
 def test_gemm_bf16_residual_in_place(M, N, K):
     """The bf16 residual stream: C = bf16(x @ w.T + b + float(C)), rounded once, C updated in place."""
@@ -279,6 +304,16 @@ def test_gemm_rejects_bad_shapes():
     w = _rand((16, 48), 2, dtype=torch.bfloat16)
     with pytest.raises(RuntimeError, match="multiple of 64"):
         ops.linear(x, w)
+    # SwiGLU epilogue: bf16 [M, N / 2] output only, no residual, N % 32 == 0 (host wrapper and C ABI both refuse)
+    x2, w2 = _rand((8, 64), 1, dtype=torch.bfloat16), _rand((48, 64), 2, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="swiglu"):
+        ops.linear(x2, w2, act="swiglu")
+    out = torch.empty((8, 32), dtype=torch.float32, device=DEV)
+    w3 = _rand((64, 64), 2, dtype=torch.bfloat16)
+    d = ops.gemm_desc(x2.data_ptr(), w3.data_ptr(), out.data_ptr(), 8, 64, 64, a_rows=(64, 0, 0), c_rows=(32, 0, 0),
+                      act=L.HK_ACT_SWIGLU, out_f32=True)
+    with pytest.raises(RuntimeError, match="HK_ACT_SWIGLU"):
+        ops.run_gemm(d)
 
 
 def _attn_ref(q, k, v, key_bias=None):
