@@ -295,6 +295,285 @@ __global__ __launch_bounds__(256) void attn_train_bwd_q_kernel(AttnT p) {
         }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Round 3: key-split forms of the forward and of the query-side backward.  The kernels above give a workgroup 64 queries
+// and walk ALL keys in 64-key tiles with two workgroup barriers and a synchronous global load per tile: at the stage-3
+// shapes (B = 2: 48 workgroups; cross-attention 37 tiles, twice) they are one long latency chain on a fifth of the chip
+// -- 3.4 ms of a 14 ms step.  Here a workgroup owns 16 queries and its four waves take the key tiles round-robin
+// (tile kt on wave kt % 4), each wave on LDS of its own, so the loop has no workgroup barrier and the next tile's loads are
+// in flight while a tile is computed; the waves' results meet once per pass through LDS, in wave order (bit-reproducible).
+// Everything is computed TRANSPOSED, as in the inference kernel:
+//     S^T = K Q^T : A = K rows (key 16 cb + lr), B = Q row of the lane's query -- both contraction-contiguous in global
+//                   memory, loaded straight into fragments (no LDS);  C: lane = query lr, keys 16 cb + 4 lg + r
+//     O^T = V^T P^T, dQ^T = K^T dS^T : B = the S^T-shaped tile as it lies in the accumulators (contraction element e of
+//                   lane group lg = key 32 step + 16 (e >> 2) + 4 lg + (e & 3)); A = V / K tile staged ROW-MAJOR in the
+//                   wave's LDS and read with ds_read_b64_tr_b16 at exactly those rows -- no transposed copy, no P tile
+//     C: lane = query lr, d = 16 db + 4 lg + r: 8-byte bf16 / 16-byte fp32 stores of one row.
+// Dropout indices and the saved statistic are those of the kernels above (the key-side backward regenerates the same mask).
+// ------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+struct alignas(16) WaveTile { __bf16 t[64][TS]; };
+
+// the wave's 8 key fragments of tile kt: rows past Nk read row Nk - 1 (finite; their scores get bias -inf)
+__device__ __forceinline__ void load_rows_frag(const __bf16* base, int64_t ld, int kt, int Nk, int lr, int lg, bf16x8 (&f)[4][2]) {
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        const __bf16* r = base + (int64_t)min(kt * 64 + 16 * cb + lr, Nk - 1) * ld + 8 * lg;
+        f[cb][0] = *reinterpret_cast<const bf16x8*>(r);
+        f[cb][1] = *reinterpret_cast<const bf16x8*>(r + 32);
+    }
+}
+// A operand of a "tile^T . X" product for contraction step `step` (32 keys) and 16-column block db, from a row-major tile
+__device__ __forceinline__ bf16x8 frag_tr(const WaveTile& t, int step, int db, int lane) {
+    const int lg = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+    const __bf16* a = &t.t[32 * step + 4 * lg + qq][16 * db + 4 * pp];
+    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)(a));
+    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)(a + 16 * TS));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+__device__ __forceinline__ void key_bias4(const AttnT& p, int b, int kt, int lg, float (&kb)[4][4]) {
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = kt * 64 + 16 * cb + 4 * lg + r;
+            kb[cb][r] = key < p.Nk ? (p.kbias ? p.kbias[(int64_t)b * p.Nk + key] * HK_LOG2E : 0.f) : -INFINITY;
+        }
+}
+__device__ __forceinline__ bf16x8 pack8(const f32x4 a, const f32x4 b) {
+    return bf16x8{(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3], (__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
+}
+
+__global__ __launch_bounds__(256) void attn_train_fwd_ks_kernel(AttnT p) {
+    __shared__ WaveTile sV[4];
+    __shared__ float sStat[4][16][2];
+    __shared__ __attribute__((aligned(16))) float sO[4][16][64];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, lr = lane & 15, lg = lane >> 4;
+    const int q0 = blockIdx.x * 16, h = blockIdx.y, b = blockIdx.z;
+    const int q = q0 + lr;
+    const __bf16* Kb = p.K + (int64_t)b * p.bsk + h * 64;
+    const __bf16* Vb = p.V + (int64_t)b * p.bsv + h * 64;
+    const __bf16* qp = p.Q + (int64_t)b * p.bsq + h * 64 + (int64_t)min(q, p.Nq - 1) * p.ldq + 8 * lg;
+    const bf16x8 bq0 = *reinterpret_cast<const bf16x8*>(qp), bq1 = *reinterpret_cast<const bf16x8*>(qp + 32);
+    const int nkt = (p.Nk + 63) / 64;
+    // ---- pass 1: row maximum and sum of this wave's tiles ----
+    float m = -INFINITY, s = 0.f;
+    bf16x8 kf[4][2], kn[4][2];
+    if (w < nkt) load_rows_frag(Kb, p.ldk, w, p.Nk, lr, lg, kf);
+    for (int kt = w; kt < nkt; kt += 4) {
+        if (kt + 4 < nkt) load_rows_frag(Kb, p.ldk, kt + 4, p.Nk, lr, lg, kn);
+        float kb[4][4];
+        key_bias4(p, b, kt, lg, kb);
+        f32x4 acc[4];
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            acc[cb] = mfma16(kf[cb][0], bq0, f32x4{0, 0, 0, 0});
+            acc[cb] = mfma16(kf[cb][1], bq1, acc[cb]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[cb][r] += kb[cb][r];
+                tmax = fmaxf(tmax, acc[cb][r]);
+            }
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float mn = fmaxf(m, tmax);
+        float ts = 0.f;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ts += exp2f(acc[cb][r] - mn);
+        ts += __shfl_xor(ts, 16);
+        ts += __shfl_xor(ts, 32);
+        s = s * exp2f(m - mn) + ts;
+        m = mn;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) kf[cb][0] = kn[cb][0], kf[cb][1] = kn[cb][1];
+    }
+    if (lg == 0) {
+        sStat[w][lr][0] = m;
+        sStat[w][lr][1] = s;
+    }
+    __syncthreads();
+    float mg = -INFINITY, sg = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) mg = fmaxf(mg, sStat[ww][lr][0]);
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) sg += sStat[ww][lr][1] * exp2f(sStat[ww][lr][0] - mg);    // a wave without tiles: 0 * 2^-inf
+    const float lse2 = mg + log2f(sg);
+    if (w == 0 && lg == 0 && q < p.Nq) p.lse[((int64_t)b * p.H + h) * p.Nq + q] = lse2;
+    // ---- pass 2: P^T = dropout(2^(S^T - lse)), O^T += V^T P^T ----
+    f32x4 o[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) o[db] = f32x4{0, 0, 0, 0};
+    bf16x8 vr[8], vn[8];
+    auto load_v = [&](int kt, bf16x8(&v)[8]) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int ch = lane + 64 * it;
+            v[it] = *reinterpret_cast<const bf16x8*>(Vb + (int64_t)min(kt * 64 + (ch >> 3), p.Nk - 1) * p.ldv + (ch & 7) * 8);
+        }
+    };
+    if (w < nkt) {
+        load_rows_frag(Kb, p.ldk, w, p.Nk, lr, lg, kf);
+        load_v(w, vr);
+    }
+    for (int kt = w; kt < nkt; kt += 4) {
+        if (kt + 4 < nkt) {
+            load_rows_frag(Kb, p.ldk, kt + 4, p.Nk, lr, lg, kn);
+            load_v(kt + 4, vn);
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int ch = lane + 64 * it;
+            *reinterpret_cast<bf16x8*>(&sV[w].t[ch >> 3][(ch & 7) * 8]) = vr[it];
+        }
+        float kb[4][4];
+        key_bias4(p, b, kt, lg, kb);
+        f32x4 pr[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            f32x4 acc = mfma16(kf[cb][0], bq0, f32x4{0, 0, 0, 0});
+            acc = mfma16(kf[cb][1], bq1, acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = exp2f(acc[r] + kb[cb][r] - lse2);
+                if (p.thresh) {
+                    const int key = kt * 64 + 16 * cb + 4 * lg + r;
+                    const uint32_t idx = (uint32_t)(((int64_t)b * p.H + h) * p.Nq + q) * (uint32_t)p.Nk + (uint32_t)key;
+                    v = keep_at(idx, p.key, p.thresh) ? v * p.inv_keep : 0.f;
+                }
+                pr[cb][r] = v;
+            }
+        }
+        const bf16x8 bp0 = pack8(pr[0], pr[1]), bp1 = pack8(pr[2], pr[3]);
+        asm volatile("" ::: "memory");   // the tile's LDS writes stay ahead of the transposed reads (one wave: LDS runs in order)
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            o[db] = mfma16(frag_tr(sV[w], 0, db, lane), bp0, o[db]);
+            o[db] = mfma16(frag_tr(sV[w], 1, db, lane), bp1, o[db]);
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) kf[cb][0] = kn[cb][0], kf[cb][1] = kn[cb][1];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) vr[it] = vn[it];
+    }
+#pragma unroll
+    for (int db = 0; db < 4; ++db) *reinterpret_cast<f32x4*>(&sO[w][lr][16 * db + 4 * lg]) = o[db];
+    __syncthreads();
+    {
+        const int qi = tid >> 4, d4 = (tid & 15) * 4, qq = q0 + qi;
+        f32x4 v = *reinterpret_cast<const f32x4*>(&sO[0][qi][d4]);
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) v += *reinterpret_cast<const f32x4*>(&sO[ww][qi][d4]);
+        if (qq < p.Nq) {
+            *reinterpret_cast<bf16x4_t*>(p.O + (int64_t)b * p.bso + h * 64 + (int64_t)qq * p.ldo + d4) =
+                bf16x4_t{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+            if (p.O32) *reinterpret_cast<f32x4*>(p.O32 + (((int64_t)b * p.Nq + qq) * p.H + h) * 64 + d4) = v;
+        }
+    }
+}
+
+// query-side backward, key-split: dsum[q] = sum_d dO.O (fp32 O), dQ = softmax_scale * dS K
+__global__ __launch_bounds__(256) void attn_train_bwd_q_ks_kernel(AttnT p) {
+    __shared__ WaveTile sK[4];
+    __shared__ __attribute__((aligned(16))) float sO[4][16][64];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, lr = lane & 15, lg = lane >> 4;
+    const int q0 = blockIdx.x * 16, h = blockIdx.y, b = blockIdx.z;
+    const int q = q0 + lr, qc = min(q, p.Nq - 1);
+    const __bf16* Kb = p.K + (int64_t)b * p.bsk + h * 64;
+    const __bf16* Vb = p.V + (int64_t)b * p.bsv + h * 64;
+    const __bf16* qp = p.Q + (int64_t)b * p.bsq + h * 64 + (int64_t)qc * p.ldq + 8 * lg;
+    const __bf16* gp = p.dO + (int64_t)b * p.bso + h * 64 + (int64_t)qc * p.ldo + 8 * lg;
+    const bf16x8 bq0 = *reinterpret_cast<const bf16x8*>(qp), bq1 = *reinterpret_cast<const bf16x8*>(qp + 32);
+    const bf16x8 bg0 = *reinterpret_cast<const bf16x8*>(gp), bg1 = *reinterpret_cast<const bf16x8*>(gp + 32);
+    float dsm = 0.f;
+    if (p.O32) {
+        const float* orow = p.O32 + (((int64_t)b * p.Nq + qc) * p.H + h) * 64 + 8 * lg;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dsm += (float)bg0[e] * orow[e] + (float)bg1[e] * orow[32 + e];
+    } else {
+        const __bf16* orow = p.O + (int64_t)b * p.bso + h * 64 + (int64_t)qc * p.ldo + 8 * lg;
+        const bf16x8 o0 = *reinterpret_cast<const bf16x8*>(orow), o1 = *reinterpret_cast<const bf16x8*>(orow + 32);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dsm += (float)bg0[e] * (float)o0[e] + (float)bg1[e] * (float)o1[e];
+    }
+    dsm += __shfl_xor(dsm, 16);
+    dsm += __shfl_xor(dsm, 32);
+    if (w == 0 && lg == 0 && q < p.Nq) p.dsum[((int64_t)b * p.H + h) * p.Nq + q] = dsm;
+    const float lse2 = p.lse[((int64_t)b * p.H + h) * p.Nq + qc];
+    f32x4 dq[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) dq[db] = f32x4{0, 0, 0, 0};
+    const int nkt = (p.Nk + 63) / 64;
+    bf16x8 kf[4][2], kn[4][2], vf[4][2], vn[4][2];
+    if (w < nkt) {
+        load_rows_frag(Kb, p.ldk, w, p.Nk, lr, lg, kf);
+        load_rows_frag(Vb, p.ldv, w, p.Nk, lr, lg, vf);
+    }
+    for (int kt = w; kt < nkt; kt += 4) {
+        if (kt + 4 < nkt) {
+            load_rows_frag(Kb, p.ldk, kt + 4, p.Nk, lr, lg, kn);
+            load_rows_frag(Vb, p.ldv, kt + 4, p.Nk, lr, lg, vn);
+        }
+        // the K fragments are rows of the tile: the same registers fill the row-major LDS tile for K^T
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            *reinterpret_cast<bf16x8*>(&sK[w].t[16 * cb + lr][8 * lg]) = kf[cb][0];
+            *reinterpret_cast<bf16x8*>(&sK[w].t[16 * cb + lr][8 * lg + 32]) = kf[cb][1];
+        }
+        float kb[4][4];
+        key_bias4(p, b, kt, lg, kb);
+        f32x4 ds[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            f32x4 acc = mfma16(kf[cb][0], bq0, f32x4{0, 0, 0, 0});
+            acc = mfma16(kf[cb][1], bq1, acc);
+            f32x4 dp = mfma16(vf[cb][0], bg0, f32x4{0, 0, 0, 0});
+            dp = mfma16(vf[cb][1], bg1, dp);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pr = exp2f(acc[r] + kb[cb][r] - lse2);
+                float g = dp[r];
+                if (p.thresh) {
+                    const int key = kt * 64 + 16 * cb + 4 * lg + r;
+                    const uint32_t idx = (uint32_t)(((int64_t)b * p.H + h) * p.Nq + q) * (uint32_t)p.Nk + (uint32_t)key;
+                    g = keep_at(idx, p.key, p.thresh) ? g * p.inv_keep : 0.f;
+                }
+                ds[cb][r] = pr * (g - dsm);
+            }
+        }
+        const bf16x8 bs0 = pack8(ds[0], ds[1]), bs1 = pack8(ds[2], ds[3]);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            dq[db] = mfma16(frag_tr(sK[w], 0, db, lane), bs0, dq[db]);
+            dq[db] = mfma16(frag_tr(sK[w], 1, db, lane), bs1, dq[db]);
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            kf[cb][0] = kn[cb][0], kf[cb][1] = kn[cb][1];
+            vf[cb][0] = vn[cb][0], vf[cb][1] = vn[cb][1];
+        }
+    }
+#pragma unroll
+    for (int db = 0; db < 4; ++db) *reinterpret_cast<f32x4*>(&sO[w][lr][16 * db + 4 * lg]) = dq[db];
+    __syncthreads();
+    {
+        const int qi = tid >> 4, d4 = (tid & 15) * 4, qq = q0 + qi;
+        f32x4 v = *reinterpret_cast<const f32x4*>(&sO[0][qi][d4]);
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) v += *reinterpret_cast<const f32x4*>(&sO[ww][qi][d4]);
+        v *= p.sm_scale;
+        if (qq < p.Nq)
+            *reinterpret_cast<bf16x4_t*>(p.dQ + (int64_t)b * p.bsdq + h * 64 + (int64_t)qq * p.lddq + d4) =
+                bf16x4_t{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    }
+}
+
 // backward, key side: dV = P~^T dO, dK = ln2 * dS^T Q' (Q' carries softmax_scale * log2 e); one workgroup per 64 keys
 __global__ __launch_bounds__(256) void attn_train_bwd_kv_kernel(AttnT p) {
     __shared__ __attribute__((aligned(16))) __bf16 sQ[64][TS];
@@ -802,12 +1081,25 @@ int fill_attn(const hk_attn_train_desc* d, AttnT& p, bool bwd, const char* who) 
     return HK_OK;
 }
 
+bool attn_ks() {
+    static const bool on = !(getenv("HK_ATTN_TRAIN_KS") && atoi(getenv("HK_ATTN_TRAIN_KS")) == 0);
+    return on;
+}
+
 }  // namespace
 
 extern "C" int hk_attn_train_fwd(const hk_attn_train_desc* d, void* stream) {
     AttnT p;
     const int rc = fill_attn(d, p, false, "hk_attn_train_fwd");
     if (rc != HK_OK) return rc;
+    // key-split form (16 queries per workgroup, waves over the key tiles) unless switched off or the fp32 copy of O is
+    // not 16-byte aligned; HK_ATTN_TRAIN_KS=0: the round-2 kernels (A/B aid)
+    if (attn_ks() && (uintptr_t)d->o_f32 % 16 == 0) {
+        hipLaunchKernelGGL(attn_train_fwd_ks_kernel, dim3((d->Nq + 15) / 16, d->H, d->B), dim3(256), 0,
+                           reinterpret_cast<hipStream_t>(stream), p);
+        HK_CHECK_LAUNCH("hk_attn_train_fwd");
+        return HK_OK;
+    }
     hipLaunchKernelGGL(attn_train_fwd_kernel, dim3((d->Nq + 63) / 64, d->H, d->B), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), p);
     HK_CHECK_LAUNCH("hk_attn_train_fwd");
@@ -823,7 +1115,10 @@ extern "C" int hk_attn_train_bwd(const hk_attn_train_desc* d, void* stream) {
     HK_REQUIRE(d->lddq >= (int64_t)d->H * 64 && d->lddk >= (int64_t)d->H * 64 && d->lddv >= (int64_t)d->H * 64,
                "hk_attn_train_bwd: gradient row strides smaller than H*64");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(attn_train_bwd_q_kernel, dim3((d->Nq + 63) / 64, d->H, d->B), dim3(256), 0, s, p);
+    if (attn_ks() && d->lddq % 4 == 0 && d->bsdq % 4 == 0 && (uintptr_t)d->dQ % 8 == 0)
+        hipLaunchKernelGGL(attn_train_bwd_q_ks_kernel, dim3((d->Nq + 15) / 16, d->H, d->B), dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL(attn_train_bwd_q_kernel, dim3((d->Nq + 63) / 64, d->H, d->B), dim3(256), 0, s, p);
     HK_CHECK_LAUNCH("hk_attn_train_bwd(q)");
     hipLaunchKernelGGL(attn_train_bwd_kv_kernel, dim3((d->Nk + 63) / 64, d->H, d->B), dim3(256), 0, s, p);
     HK_CHECK_LAUNCH("hk_attn_train_bwd(kv)");

@@ -160,6 +160,11 @@ class _TrainPlan:
         self.marks: List[Tuple[int, int]] = []   # (index into bwd after which ..., gradient arena offset finished)
         self.stamp: Optional[Tuple[int, int]] = None   # (inference-engine calls, training forwards) after this plan's forward
         self.unused: frozenset = frozenset()     # trainable parameters this shape never touches (gradient None)
+        # Weight gradients beside the dgrad chain (a second stream): bwd index of a wgrad step -> name of the dY buffer it reads;
+        # bwd index of a step that OVERWRITES such a buffer -> its name (that step first waits for the wgrad still reading it)
+        self.bwd_side: Dict[int, str] = {}
+        self.bwd_writes: Dict[int, str] = {}
+        self.bwd_events: Dict[int, Tuple] = {}   # wgrad step -> (fork event, done event), made on first use
 
     def buf(self, name, shape, dtype, device):
         t = self.pool.view(name, shape, dtype) if self.pool is not None else torch.empty(shape, dtype=dtype, device=device)
@@ -190,6 +195,12 @@ class QFormerTrainEngine:
         # (engine._Pool): one training call is in flight per engine, whatever its shape
         self.pool = _Pool(self.device)
         self.forwards = 0
+        # HK_WGRAD_SIDE=1: weight gradients on a second stream beside the dgrad chain (fork / join by events, same bits:
+        # tests/test_gpu_train.py).  MEASURED SLOWER at the stage-3 shape and therefore off: B = 2, T = 12 step 12.28 -> 12.58 ms,
+        # backward 3.58 -> 3.63 ms (device span unchanged, host enqueue 1.0 -> 3.1 ms for the 168 event calls): the wgrad
+        # launches are 7-9 us on 36-144 workgroups and the cross-queue event hand-offs cost the chain as much as they free.
+        self.wgrad_side = os.environ.get("HK_WGRAD_SIDE", "0") == "1"
+        self._side: Optional["torch.cuda.Stream"] = None
         self._build_pack()
 
     # ------------------------------------------------------------------ weights
@@ -439,6 +450,8 @@ class QFormerTrainEngine:
 
         # ------------------------------------------------------------ backward
         Bw = plan.bwd
+        # the bf16 gradient buffers the weight gradients read (each is rewritten block after block by the dgrad chain)
+        dyname = {P(do_b): "do_b", P(dui): "dui", P(dcq): "dcq", P(dqkv): "dqkv", P(dout_b): "dout_b", P(dkvc): "dkvc"}
 
         def transpose(x_ptr, x_rows, rows, cols, out_ptr):
             Bw.append((lib.hk_transpose_bf16, (x_ptr, L.HK_DT_BF16, self._rows(plan, x_rows), rows, cols, out_ptr, pad64(rows)),
@@ -447,6 +460,9 @@ class QFormerTrainEngine:
         def wgrad(dy_ptr, rows, n_out, x_ptr, x_rows, k_in, wname, bname):
             """dW[n_out, k_in] = dY^T X (contraction over `rows`), db = column sums of dY."""
             if fused_wgrad:
+                # off the critical path: nothing in the backward reads a weight gradient, so the launch may run beside the
+                # dgrad chain (plan.bwd_side; backward() forks / joins by events).  x operands are saved activations.
+                plan.bwd_side[len(Bw)] = dyname[dy_ptr]
                 Bw.append((lib.hk_wgrad_bf16, (dy_ptr, n_out, x_ptr, self._rows(plan, x_rows), ar.g32(wname), k_in, ar.g32(bname),
                                                rows, n_out, k_in), "hk_wgrad_bf16"))
                 return
@@ -462,6 +478,8 @@ class QFormerTrainEngine:
                        residual=residual, r_rows=r_rows, out_f32=out_f32)
 
         def lnbwd(dy_ptr, dy_rows, z_ptr, gname, drop, post, dz_ptr, dt_ptr, rows):
+            if dt_ptr is not None:
+                plan.bwd_writes[len(Bw)] = dyname[dt_ptr]
             Bw.append((lib.hk_layernorm_bwd, (dy_ptr, self._rows(plan, dy_rows), z_ptr, ar.p32(gname + ".weight"), drop, post,
                                               dz_ptr, dt_ptr, ar.g32(gname + ".weight"), ar.g32(gname + ".bias"), P(lnws),
                                               rows, d, eps), "hk_layernorm_bwd"))
@@ -472,6 +490,7 @@ class QFormerTrainEngine:
                   self._drop(plan, self.p_hidden, site(i, kinds[0]), pr, site(i, kinds[1]), rps), None, P(dzs), P(do_b), rows)
             wgrad(P(do_b), rows, d, P(g), None, I, lname(i, blk + ".dense.weight"), lname(i, blk + ".dense.bias"))
             dgrad(P(do_b), rows, d, key_o, I, P(dgi), plain(I), out_f32=False)
+            plan.bwd_writes[len(Bw)] = "dui"
             Bw.append((lib.hk_gelu_bwd_bf16, (P(dgi), P(u), P(dui), rows * I), "hk_gelu_bwd_bf16"))
             wgrad(P(dui), rows, I, x_ptr, x_rows, d, lname(i, inter + ".dense.weight"), lname(i, inter + ".dense.bias"))
             dgrad(P(dui), rows, I, key_i, d, dst_ptr, dst_rows, residual=P(dzs), r_rows=plain(d))
@@ -499,6 +518,7 @@ class QFormerTrainEngine:
                 wgrad(P(do_b), Rq, d, P(s["cctx"]), None, d, c + "output.dense.weight", c + "output.dense.bias")
                 dgrad(P(do_b), Rq, d, f"{i}.co", d, P(dctx), plain(d), out_f32=False)
                 ci = self.cross.index(i)
+                plan.bwd_writes[len(Bw)] = "dcq"
                 attn(Bw, lib.hk_attn_train_bwd, dO=P(dctx), dQ=P(dcq), dK=P(dkvc) + ci * 2 * d * 2,
                      dV=P(dkvc) + (ci * 2 + 1) * d * 2, dsum=P(dsum), lddq=d, lddk=KVW, lddv=KVW, bsdq=nq * d, bsdk=N * KVW,
                      bsdv=N * KVW, **cross_attn_args(i))
@@ -509,6 +529,7 @@ class QFormerTrainEngine:
                   self._drop(plan, self.p_hidden, site(i, SELF_HID), pr, site(i, SELF_PATH), S), None, P(dzs), P(do_b), R)
             wgrad(P(do_b), R, d, P(s["ctx"]), None, d, a + "output.dense.weight", a + "output.dense.bias")
             dgrad(P(do_b), R, d, f"{i}.ao", d, P(dctx), plain(d), out_f32=False)
+            plan.bwd_writes[len(Bw)] = "dqkv"
             attn(Bw, lib.hk_attn_train_bwd, dO=P(dctx), dQ=P(dqkv), dK=P(dqkv) + 2 * d, dV=P(dqkv) + 4 * d, dsum=P(dsum),
                  lddq=3 * d, lddk=3 * d, lddv=3 * d, bsdq=S * 3 * d, bsdk=S * 3 * d, bsdv=S * 3 * d, **self_attn_args(i))
             wgrad(P(dqkv), R, 3 * d, P(hb[i]), None, d, a + "self.query.weight", a + "self.query.bias")
@@ -620,12 +641,54 @@ class QFormerTrainEngine:
             plan.ws["da"].zero_()
             fn, args, name = plan.bwd[0]
             plan.bwd[0] = (fn, (dout.data_ptr(),) + tuple(args[1:]), name)
+            side_on = self.wgrad_side and bool(plan.bwd_side)
             lo = 0
-            for hi, done in plan.marks:
-                self._run(plan.bwd, stream, lo, hi)
-                lo = hi
-                if reducer is not None:
-                    reducer.ready(done)
+            if not side_on:
+                for hi, done in plan.marks:
+                    self._run(plan.bwd, stream, lo, hi)
+                    lo = hi
+                    if reducer is not None:
+                        reducer.ready(done)
+            else:
+                # The dgrad chain (LayerNorm / GELU / attention backward, dX GEMMs) is a string of small dependent launches;
+                # the weight gradients hang off it and nothing downstream reads them.  They go to a second stream: fork =
+                # an event on the caller's stream where the wgrad stood (its dY is complete there), join = the step that
+                # next overwrites that dY buffer waits for the wgrad's done-event; every gradient range handed to the
+                # reducer, and the end of the call, wait for the side stream's last launch (it runs in order).
+                main = torch.cuda.current_stream()
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=self.device)
+                side, side_h = self._side, self._side.cuda_stream
+                pending: Dict[str, "torch.cuda.Event"] = {}
+                last = None
+                for hi, done in plan.marks:
+                    for idx in range(lo, hi):
+                        fn, args, name = plan.bwd[idx]
+                        key = plan.bwd_side.get(idx)
+                        if key is not None:
+                            ev = plan.bwd_events.get(idx)
+                            if ev is None:
+                                ev = plan.bwd_events[idx] = (torch.cuda.Event(), torch.cuda.Event())
+                            ev[0].record(main)
+                            side.wait_event(ev[0])
+                            rc = fn(*args, side_h)
+                            ev[1].record(side)
+                            pending[key] = last = ev[1]
+                        else:
+                            w = plan.bwd_writes.get(idx)
+                            if w is not None and w in pending:
+                                main.wait_event(pending.pop(w))
+                            rc = fn(*args, stream)
+                        if rc != 0:
+                            L.check(rc, name)
+                    lo = hi
+                    if reducer is not None:
+                        if last is not None:
+                            main.wait_event(last)
+                            pending.clear()
+                        reducer.ready(done)
+                if last is not None:
+                    main.wait_event(last)
             if reducer is not None:
                 reducer.finish()
         return ar.grad

@@ -45,7 +45,7 @@ def test_device_dropout_mask_equals_numpy_restatement():
 
 @pytest.mark.parametrize("B,H,Nq,Nk,p,bias", [(2, 2, 24, 24, 0.0, True), (2, 12, 128, 128, 0.1, True),
                                               (1, 3, 96, 400, 0.1, False), (2, 2, 16, 197, 0.25, False),
-                                              (1, 2, 130, 70, 0.1, True)])
+                                              (1, 2, 130, 70, 0.1, True), (2, 12, 96, 2353, 0.1, False), (1, 1, 5, 30, 0.0, True)])
 def test_attention_train_fwd_bwd(B, H, Nq, Nk, p, bias):
     seed, site = 99, DM.site(3, DM.SELF_PROB)
     scale = 1.0 / 8.0
