@@ -12,7 +12,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from hawkeye_amd import ops  # noqa: E402
+from hawkeye_amd import lib as L, ops  # noqa: E402
 
 DEV = "cuda:0"
 
