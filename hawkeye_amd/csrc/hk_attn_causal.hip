@@ -111,7 +111,10 @@ __global__ __launch_bounds__(256, HK_CAUSAL_OCC) void hk_attn_causal_kernel(cons
         for (int i = 0; i < PASSES; ++i) {
             const int key = i * KPP + lkey;
             *reinterpret_cast<bf16x8*>(ks + key * ROWB + ((lc ^ (key & (CH - 1))) << 4)) = kr[i];
-            *reinterpret_cast<bf16x8*>(vs + key * ROWB + (lc << 4)) = vr[i];
+            // V: 16-byte chunk c of key row k lives at c ^ ((k % (CH / 2)) << 1) -- the 8 key rows one transposed read touches
+            // (4 h + vq, 256-byte rows: all on the same banks unswizzled, 48 % conflict cycles in the r03 counter pass) spread
+            // over distinct 32-byte bank groups
+            *reinterpret_cast<bf16x8*>(vs + key * ROWB + ((lc ^ ((key & (CH / 2 - 1)) << 1)) << 4)) = vr[i];
         }
         if (HAS_BIAS && tid < KT) bias_lds[stage * KT + tid] = br;
     };
@@ -122,7 +125,10 @@ __global__ __launch_bounds__(256, HK_CAUSAL_OCC) void hk_attn_causal_kernel(cons
     const int vq = (lane & 15) >> 2;
     int voff[NDT];
 #pragma unroll
-    for (int dt = 0; dt < NDT; ++dt) voff[dt] = (4 * h + vq) * ROWB + 64 * dt + 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
+    for (int dt = 0; dt < NDT; ++dt) {
+        const int chunk = 4 * dt + 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);     // (rows read are 4 h + vq + 8 n: same swizzle)
+        voff[dt] = (4 * h + vq) * ROWB + ((chunk ^ (((4 * h + vq) & (CH / 2 - 1)) << 1)) << 4) + 8 * (lane & 1);
+    }
 
     f32x16 ot[NDT];
 #pragma unroll
