@@ -1533,6 +1533,12 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
     auto small = [&](const GemmParams& q) {
         if (mid_window(q.M)) return launch<256, 128, 4, 2, 2>(q, s);   // also the tail rows of a split persistent launch
         const long t128 = (long)((q.M + 127) / 128) * ((q.N + 127) / 128);
+        // half a chip of 128x128 tiles or less that 128x64 tiles spread over (nearly) all CUs in one round -- the tail rows of a
+        // split persistent launch (2048 x 1024 at the headline shape: 128 -> 256 workgroups): four waves of 32 x 64, which
+        // keeps the 64-column row_part granule.  HK_GEMM_TAIL64=0: off (A/B aid)
+        static const int tail64 = getenv("HK_GEMM_TAIL64") ? atoi(getenv("HK_GEMM_TAIL64")) : 1;
+        const long t64 = (long)((q.M + 127) / 128) * ((q.N + 63) / 64);
+        if (tail64 != 0 && q.row_part && t128 <= 128 && t64 > 160 && t64 <= 256) return launch<128, 64, 4, 1, 4>(q, s);
         if (q.row_part && t128 < 384) return launch<128, 128, 2, 2, 4>(q, s);  // 64 columns per wave: the row_part granule
         if (t128 >= 384) return launch<128, 128, 2, 2, 2>(q, s);  // >= 1.5 workgroups per CU: 2 stages, 2 workgroups per CU
         if (t128 >= 128) return launch<128, 128, 2, 2, 4>(q, s);

@@ -208,7 +208,8 @@ def test_gemm_with_folded_layernorm(M, N, K, act):
 
 
 @pytest.mark.parametrize("M,N,K", [(512, 1024, 256), (100352 // 2 + 3, 1024, 1024), (300, 256, 128), (66000, 1024, 128),
-                                   (5000 - 9, 1024, 256)])   # the last: one round of 256x128 tiles (160)
+                                   (5000 - 9, 1024, 256),    # one round of 256x128 tiles (160)
+                                   (2048, 1024, 192), (1990, 1024, 64), (100352, 1024, 64)])   # 256 tiles of 128x64 (the headline shape's tail rows)
 def test_gemm_row_part_feeds_the_next_layernorm(M, N, K):
     """row_part of the in-place residual epilogue (persistent kernel, its split tail and the small kernel) ->
     hk_row_stats_finalize == the statistics hk_row_stats takes from the stored bf16 rows: the sums are taken from
