@@ -1530,8 +1530,16 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
         static const int mid_lo = getenv("HK_GEMM_MID_LO") ? atoi(getenv("HK_GEMM_MID_LO")) : 144;   // see the rule below
         return mid != 0 && variant != 0 && tiles_mid <= 256 && tiles_mid >= mid_lo;
     };
+    // HK_GEMM_192=0 turns the 192-row tiles off (A/B aid); 2 / 3: experiments (below)
+    static const int r192 = getenv("HK_GEMM_192") ? atoi(getenv("HK_GEMM_192")) : 1;
+    // rows a tile height pads M to: 192-row tiles waste less on skinny problems (M = 352, a B = 1 prompt: 384 rows instead of 512)
+    auto padded = [](int M_, int bm) { return (M_ + bm - 1) / bm * bm; };
     auto small = [&](const GemmParams& q) {
-        if (mid_window(q.M)) return launch<256, 128, 4, 2, 2>(q, s);   // also the tail rows of a split persistent launch
+        if (mid_window(q.M)) {   // also the tail rows of a split persistent launch
+            const long t192 = (long)((q.M + 191) / 192) * ((d->N + 127) / 128);
+            if (r192 != 0 && padded(q.M, 192) < padded(q.M, 256) && t192 <= 256) return launch<192, 128, 4, 2, 2>(q, s);
+            return launch<256, 128, 4, 2, 2>(q, s);
+        }
         const long t128 = (long)((q.M + 127) / 128) * ((q.N + 127) / 128);
         // half a chip of 128x128 tiles or less that 128x64 tiles spread over (nearly) all CUs in one round -- the tail rows of a
         // split persistent launch (2048 x 1024 at the headline shape: 128 -> 256 workgroups): four waves of 32 x 64, which
@@ -1571,7 +1579,11 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
         // slices 50.4 -> 37.4 us with the consumer's sum (unsplit 45.6 + 4.7), M = 3136 in 2 slices 60.1 -> 45.0 (46.9 + 4.7),
         // M = 1568 in 4 slices 40.3 -> 30.1 (2 slices of 128x128 tiles: 33.0); HK_GEMM_MID=0 turns it off
         const long tmid = (long)((d->M + 255) / 256) * ((d->N + 127) / 128) * p.ksplit;
-        if (mid != 0 && tmid >= 160 && tmid <= 256) return launch<256, 128, 4, 2, 2>(p, s);
+        if (mid != 0 && tmid >= 160 && tmid <= 256) {
+            const long t192 = (long)((d->M + 191) / 192) * ((d->N + 127) / 128) * p.ksplit;
+            if (r192 != 0 && padded(d->M, 192) < padded(d->M, 256) && t192 <= 256) return launch<192, 128, 4, 2, 2>(p, s);
+            return launch<256, 128, 4, 2, 2>(p, s);
+        }
         if (t128 >= 384) return launch<128, 128, 2, 2, 2>(p, s);
         if (t128 >= 128) return launch<128, 128, 2, 2, 4>(p, s);
         return launch<128, 64, 2, 2, 4>(p, s);
@@ -1585,12 +1597,13 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
     // on: B = 2 T = 16 10.58 -> 9.48 ms, B = 4 T = 8 9.43 -> 8.35, B = 3 T = 12 10.05 -> 9.01; lower bound 160 -> 144: B = 2 T = 12
     // 8.14 -> 7.55, B = 1 T = 7 4.53 -> 4.30.  Two or three rounds of these tiles for the N = 1024 layers (257-768 tiles, in place
     // of a persistent round plus its tail) lose: B = 4 T = 12 11.47 -> 12.2 ms, B = 6 T = 12 14.86 -> 15.9, B = 8 T = 12 20.3 -> 20.95.
-    static const int r192 = getenv("HK_GEMM_192") ? atoi(getenv("HK_GEMM_192")) : 1;
     const long tiles192 = (long)((d->M + 191) / 192) * ((d->N + 255) / 256);
     const int epi = p.act == HK_ACT_SWIGLU ? 5 : p.row_stats ? 3 : (!p.out_f32 && !p.res) ? 0 : (!p.out_f32 && p.res_bf16) ? (p.row_part ? 4 : 2) : 1;
     // HK_GEMM_192=2 (experiments): the 192-row tile for every launch it covers in one round, before the other small-shape rules
-    if (r192 == 2 && variant != 0 && d->N % 256 == 0 && off32 && tiles192 <= 256 && (epi == 0 || epi == 1))
-        return epi == 0 ? launch_pp<0, 3>(p, s) : launch_pp<1, 3>(p, s);
+    if (r192 == 2 && variant != 0 && d->N % 256 == 0 && off32 && tiles192 <= 256 && (epi == 0 || epi == 1 || epi == 5))
+        return epi == 0 ? launch_pp<0, 3>(p, s) : epi == 1 ? launch_pp<1, 3>(p, s) : launch_pp<5, 3>(p, s);
+    // HK_GEMM_192=3 (experiments): the multi-stage kernel on 192x128 tiles
+    if (r192 == 3 && d->split_k <= 1) return launch<192, 128, 4, 2, 2>(p, s);
     if (mid_window(d->M)) return small(p);
     if (variant != 0 && tiles256 >= pp_min && d->N % 256 == 0 && off32) {
         // Tail balance: the persistent kernel gives each of the 256 CUs floor or ceil(tiles / 256) tiles, so a
@@ -1635,8 +1648,10 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
         // One partial round of 256-row tiles (tiles256 < CUs) that 192-row tiles still cover in one round: the round then
         // takes 3/4 of the time on more of the chip (prefill o_proj / down_proj at M = 2816: 176 -> 240 workgroups).
         // HK_GEMM_192=0 turns the rule off (A/B aid).  Instantiated for the epilogue kinds that meet such shapes.
-        if (r192 != 0 && tail.M == 0 && !use_duo && tiles256 < ncu && tiles192 <= ncu && tiles192 > tiles256 && (epi == 0 || epi == 1)) {
-            return epi == 0 ? launch_pp<0, 3>(p, s) : launch_pp<1, 3>(p, s);
+        // ... or cover it with as many workgroups and fewer padded rows (M = 352, gate | up: 172 workgroups either way, 384 rows)
+        if (r192 != 0 && tail.M == 0 && !use_duo && tiles256 < ncu && tiles192 <= ncu && (epi == 0 || epi == 1 || epi == 5) &&
+            (tiles192 > tiles256 || (tiles192 == tiles256 && padded(d->M, 192) < padded(d->M, 256)))) {
+            return epi == 0 ? launch_pp<0, 3>(p, s) : epi == 1 ? launch_pp<1, 3>(p, s) : launch_pp<5, 3>(p, s);
         }
         int rc;
         if (epi == 3) rc = use_duo ? launch_duo<3>(p, s) : launch_pp<3>(p, s);

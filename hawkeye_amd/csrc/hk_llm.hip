@@ -40,6 +40,59 @@ __global__ __launch_bounds__(256) void hk_rmsnorm_kernel(const void* __restrict_
     }
 }
 
+// The same norm on the sum of split-K slices (round 3, skinny prompts): x = sum_p parts[p] (slice 0 already carries the
+// residual stream, hk_gemm_desc.split_k), written back as the new fp32 residual stream, and y = RMSNorm(x) * w in bf16 --
+// the residual add of o_proj / down_proj (modeling_llama.py:297-307) and the norm that follows it in one pass.
+// One WORKGROUP per row (these launches have a few hundred rows: a wave per row left three quarters of the chip idle and each wave
+// a chain of n_parts x D / 256 dependent loads): thread t owns elements 1024 c + 4 t .. + 3, the slices' loads of a chunk are issued
+// together, the sum of squares meets through LDS.
+template <int NCH>   // chunks of 1024 elements per row (D <= 1024 NCH)
+__global__ __launch_bounds__(256) void hk_rmsnorm_parts_kernel(const float* __restrict__ parts, int n_parts, int64_t stride,
+                                                               float* __restrict__ x, const float* __restrict__ w,
+                                                               __bf16* __restrict__ out, int64_t rows, int D, float eps) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row = blockIdx.x;
+    f32x4 v[NCH];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int i = c * 1024 + tid * 4;
+        v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (i < D) {
+            const float* src = parts + row * D + i;
+            f32x4 a = *reinterpret_cast<const f32x4*>(src);
+            int q = 1;
+            for (; q + 2 < n_parts; q += 3) {   // slice order kept: ((s0 + s1) + s2) + s3 ...
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(src + q * stride);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(src + (q + 1) * stride);
+                const f32x4 b2 = *reinterpret_cast<const f32x4*>(src + (q + 2) * stride);
+                a = ((a + b0) + b1) + b2;
+            }
+            for (; q < n_parts; ++q) a += *reinterpret_cast<const f32x4*>(src + q * stride);
+            v[c] = a;
+            *reinterpret_cast<f32x4*>(x + row * D + i) = a;
+            ss += a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    const float rinv = rsqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)D + eps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int i = c * 1024 + tid * 4;
+        if (i < D) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(w + i);
+            u32x2 o;
+            o[0] = pack_bf16x2(g[0] * (v[c][0] * rinv), g[1] * (v[c][1] * rinv));
+            o[1] = pack_bf16x2(g[2] * (v[c][2] * rinv), g[3] * (v[c][3] * rinv));
+            *reinterpret_cast<u32x2*>(out + row * D + i) = o;
+        }
+    }
+}
+
 // apply_rotary_pos_emb (modeling_llama.py:116-123) on the q and k thirds of a fused [rows, 3*H*hd] bf16 buffer, in
 // place:  x' = x * cos + rotate_half(x) * sin  with rotate_half(x) = cat(-x[hd/2:], x[:hd/2]) (:108-113), cos/sin
 // rows of the cached fp32 table (:82-89) selected by position_ids.  q is also multiplied by qscale (the softmax
@@ -157,6 +210,28 @@ extern "C" int hk_rmsnorm(const void* x, int32_t in_dtype, const float* weight, 
     }
 #undef HK_RMS
     HK_CHECK_LAUNCH("hk_rmsnorm");
+    return HK_OK;
+}
+
+extern "C" int hk_rmsnorm_add_parts(const float* parts, int32_t n_parts, int64_t part_stride, float* x, const float* weight,
+                                    void* out_bf16, int64_t rows, int32_t D, float eps, void* stream) {
+    HK_REQUIRE(parts && x && weight && out_bf16, "hk_rmsnorm_add_parts: null pointer");
+    HK_REQUIRE(n_parts >= 1 && n_parts <= 64 && part_stride >= rows * D && part_stride % 4 == 0,
+               "hk_rmsnorm_add_parts: 1..64 slices, stride >= rows * D and a multiple of 4");
+    HK_REQUIRE(rows > 0 && D > 0 && D % 256 == 0 && D <= 8192, "hk_rmsnorm_add_parts: D=%d must be a multiple of 256, <= 8192", D);
+    HK_REQUIRE(((uintptr_t)parts | (uintptr_t)x | (uintptr_t)weight | (uintptr_t)out_bf16) % 16 == 0,
+               "hk_rmsnorm_add_parts: operands must be 16-byte aligned");
+    HK_REQUIRE(rows < (1L << 31), "hk_rmsnorm_add_parts: too many rows");
+    const dim3 grid((unsigned)rows);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    __bf16* o = reinterpret_cast<__bf16*>(out_bf16);
+    switch ((D + 1023) / 1024) {
+        case 1: hipLaunchKernelGGL((hk_rmsnorm_parts_kernel<1>), grid, dim3(256), 0, s, parts, n_parts, part_stride, x, weight, o, rows, D, eps); break;
+        case 2: hipLaunchKernelGGL((hk_rmsnorm_parts_kernel<2>), grid, dim3(256), 0, s, parts, n_parts, part_stride, x, weight, o, rows, D, eps); break;
+        case 3: case 4: hipLaunchKernelGGL((hk_rmsnorm_parts_kernel<4>), grid, dim3(256), 0, s, parts, n_parts, part_stride, x, weight, o, rows, D, eps); break;
+        default: hipLaunchKernelGGL((hk_rmsnorm_parts_kernel<8>), grid, dim3(256), 0, s, parts, n_parts, part_stride, x, weight, o, rows, D, eps); break;
+    }
+    HK_CHECK_LAUNCH("hk_rmsnorm_add_parts");
     return HK_OK;
 }
 

@@ -97,6 +97,8 @@ SYMBOLS = {
     "hk_rope_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "hk_silu_mul_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+    "hk_rmsnorm_add_parts": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                       C.c_int32, C.c_float, C.c_void_p]),
     "hk_embed_splice": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32,
                                   C.c_void_p]),
     "hk_qformer_embed_ln": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

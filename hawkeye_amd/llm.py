@@ -172,6 +172,21 @@ class LlamaPrefill:
         return self
 
     # ------------------------------------------------------------------ plan
+    @staticmethod
+    def split_k_for(M: int, N: int, K: int) -> int:
+        """Split-K factor of an o_proj / down_proj launch: 1 unless its 256x128 tiles fill well under the chip (M <= ~1000
+        rows); then the largest of 4 / 2 whose slices make at most one workgroup per CU and divide the K-tiles.  Isolated,
+        M = 352 (tools/skinny_split.py): o_proj 37.1 -> 28.4 us, down_proj 81.1 -> 52.0 us at 4 slices; M = 704: 54.3 -> 43.7,
+        121.7 -> 92.1 at 2.  HK_LLM_SPLIT_K=0: off."""
+        if os.environ.get("HK_LLM_SPLIT_K", "1") == "0":
+            return 1
+        tmid = -(-M // 256) * -(-N // 128)
+        kt = K // 64
+        for s in (4, 2):
+            if tmid * s <= 256 and kt % s == 0 and kt // s >= 16:
+                return s
+        return 1
+
     def _gemm(self, plan, A, W, Cout, M, N, K, **kw):
         d = ops.gemm_desc(A, W.data_ptr(), Cout, M, N, K, a_rows=(K, 0, 0), c_rows=(N, 0, 0), **kw)
         plan.keep.append(d)
@@ -201,15 +216,33 @@ class LlamaPrefill:
             ws["hl_f"] = buf("hl_f", (B, D), f32)
             ws["hl_b"] = buf("hl_b", (B, D), bf16)
             ws["logits"] = buf("logits", (B, V), f32)
+            # skinny prompts (B = 1 eval calls: M = 352 is 64 workgroups walking 64-172 K-tiles): o_proj / down_proj split over K,
+            # fp32 slices summed by the norm that follows (hk_rmsnorm_add_parts)
+            sk_o, sk_d = self.split_k_for(M, D, D), self.split_k_for(M, D, I)
+            ws["parts"] = buf("parts", (max(sk_o, sk_d), M, D), f32) if max(sk_o, sk_d) > 1 else None
         P = lambda t: t.data_ptr()  # noqa: E731
         x, xn, att, gu, act = ws["x"], ws["xn"], ws["att"], ws["gu"], ws["act"]
         qscale = (hd ** -0.5) * LOG2E
         eb = 2
+        def norm(gamma, sk):
+            """RMSNorm of the residual stream -> xn; after a split-K GEMM it first sums the slices into the stream."""
+            if sk > 1:
+                plan.steps.append((self.lib.hk_rmsnorm_add_parts, (P(ws["parts"]), sk, M * D, P(x), P(gamma), P(xn), M, D,
+                                                                   cfg.rms_norm_eps), "hk_rmsnorm_add_parts"))
+            else:
+                plan.steps.append((self.lib.hk_rmsnorm, (P(x), L.HK_DT_F32, P(gamma), P(xn), M, D, cfg.rms_norm_eps), "hk_rmsnorm"))
+
+        def residual_gemm(A, W, K, sk):
+            if sk > 1:
+                self._gemm(plan, A, W, P(ws["parts"]), M, D, K, residual=P(x), r_rows=(D, 0, 0), out_f32=True, split_k=sk,
+                           split_stride=M * D)
+            else:
+                self._gemm(plan, A, W, P(x), M, D, K, residual=P(x), r_rows=(D, 0, 0), out_f32=True)
+
         for i in range(Lyr):
             o = f"l{i}."
             qkv = ws["qkv"][i]
-            plan.steps.append((self.lib.hk_rmsnorm, (P(x), L.HK_DT_F32, P(w[o + "n1"]), P(xn), M, D, cfg.rms_norm_eps),
-                               "hk_rmsnorm"))
+            norm(w[o + "n1"], sk_d if i > 0 else 1)
             self._gemm(plan, P(xn), w[o + "qkv"], P(qkv), M, 3 * D, D)
             plan.steps.append((self.lib.hk_rope_bf16, (P(qkv), P(w["cos"]), P(w["sin"]), P(ws["pos"]) if with_pos else None, M, H, hd, S,
                                                        cfg.max_position_embeddings, qscale), "hk_rope_bf16"))
@@ -218,9 +251,8 @@ class LlamaPrefill:
                                key_bias=P(ws["kbias"]) if masked else None, head_dim=hd, causal=True)
             plan.keep.append(ad)
             plan.steps.append((self.lib.hk_flash_attn_bf16, (C.byref(ad),), "hk_flash_attn_bf16"))
-            self._gemm(plan, P(att), w[o + "o"], P(x), M, D, D, residual=P(x), r_rows=(D, 0, 0), out_f32=True)
-            plan.steps.append((self.lib.hk_rmsnorm, (P(x), L.HK_DT_F32, P(w[o + "n2"]), P(xn), M, D, cfg.rms_norm_eps),
-                               "hk_rmsnorm"))
+            residual_gemm(P(att), w[o + "o"], D, sk_o)
+            norm(w[o + "n2"], sk_o)
             if self.fused_swiglu:
                 # gate | up projections and silu(gate) * up in one launch: the [M, 2I] matrix is never written
                 d = ops.gemm_desc(P(xn), w[o + "gu"].data_ptr(), P(act), M, 2 * I, D, a_rows=(D, 0, 0), c_rows=(I, 0, 0),
@@ -230,8 +262,8 @@ class LlamaPrefill:
             else:
                 self._gemm(plan, P(xn), w[o + "gu"], P(gu), M, 2 * I, D)
                 plan.steps.append((self.lib.hk_silu_mul_bf16, (P(gu), P(act), M, I), "hk_silu_mul_bf16"))
-            self._gemm(plan, P(act), w[o + "down"], P(x), M, D, I, residual=P(x), r_rows=(D, 0, 0), out_f32=True)
-        plan.steps.append((self.lib.hk_rmsnorm, (P(x), L.HK_DT_F32, P(w["norm"]), P(xn), M, D, cfg.rms_norm_eps), "hk_rmsnorm"))
+            residual_gemm(P(act), w[o + "down"], I, sk_d)
+        norm(w["norm"], sk_d)
         # last valid position of every row -> lm_head (LlamaForCausalLM.forward :688-700; generation reads logits[:, -1])
         plan.steps.append((self.lib.hk_embed_splice, (P(ws["last"]), P(xn), None, L.HK_DT_BF16, P(ws["hl_f"]), B, D),
                            "hk_embed_splice"))

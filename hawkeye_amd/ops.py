@@ -316,6 +316,20 @@ def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float, out: Optional[tor
     return out
 
 
+def rmsnorm_add_parts(parts: torch.Tensor, weight: torch.Tensor, eps: float):
+    """Split-K slices fp32 [P, rows, D] (slice 0 carries the residual stream) -> (x fp32 [rows, D] = their sum, bf16 RMSNorm(x) * weight)."""
+    _need(parts, torch.float32, "parts")
+    _need(weight, torch.float32, "weight")
+    if parts.dim() != 3 or not parts.is_contiguous():
+        raise RuntimeError("rmsnorm_add_parts: parts must be a contiguous [P, rows, D] tensor")
+    P, rows, D = parts.shape
+    x = torch.empty((rows, D), dtype=torch.float32, device=parts.device)
+    out = torch.empty((rows, D), dtype=torch.bfloat16, device=parts.device)
+    L.check(L.load().hk_rmsnorm_add_parts(parts.data_ptr(), P, rows * D, x.data_ptr(), weight.data_ptr(), out.data_ptr(), rows, D,
+                                          eps, _stream()), "hk_rmsnorm_add_parts")
+    return x, out
+
+
 def rope_(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, H: int, head_dim: int, seq_len: int,
           q_scale: float = 1.0, position_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Rotary embedding in place on the q|k thirds of qkv bf16 [rows, 3*H*hd]; cos/sin fp32 [P, hd/2]."""

@@ -189,6 +189,13 @@ int hk_pos_embed(float* out, int32_t T, int32_t L, int32_t D, int32_t ckpt_frame
 int hk_rmsnorm(const void* x, int32_t in_dtype, const float* weight, void* out_bf16, int64_t rows, int32_t D,
                float eps, void* stream);
 
+/* The residual add of o_proj / down_proj and the RMSNorm that follows it (modeling_llama.py:297-307, 57-75) on split-K slices:
+ * x[rows, D] fp32 (out: the new residual stream) = sum over the n_parts slices of `parts` (slice q at parts + q * part_stride; slice 0
+ * of hk_gemm_bf16's split_k already carries the old residual stream), out_bf16 = RMSNorm(x) * weight.  Used for skinny prompts
+ * (B = 1 eval calls), where o_proj / down_proj are a few workgroups walking 64-172 K-tiles unless K is split. */
+int hk_rmsnorm_add_parts(const float* parts, int32_t n_parts, int64_t part_stride, float* x, const float* weight,
+                         void* out_bf16, int64_t rows, int32_t D, float eps, void* stream);
+
 /* apply_rotary_pos_emb (modeling_llama.py:108-123) in place on the q and k thirds of a fused bf16
  * [rows, 3*H*head_dim] buffer; cos/sin fp32 [table_rows, head_dim/2] (the first half of the reference's cached
  * table, :82-89, whose two halves are equal); position_ids int32 [rows] or NULL (= row % seq_len, the default

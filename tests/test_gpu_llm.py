@@ -45,6 +45,41 @@ def test_rmsnorm(D, in_bf16):
     assert _rel(out.float(), ref) < 5e-3
 
 
+@pytest.mark.parametrize("P,rows,D", [(4, 352, 4096), (2, 37, 1024), (1, 5, 256), (3, 100, 5120), (5, 9, 768)])
+def test_rmsnorm_of_summed_split_k_slices(P, rows, D):
+    """hk_rmsnorm_add_parts: the residual add of o_proj / down_proj and the norm after it, on split-K slices (slice order, fp32)."""
+    parts = _rand((P, rows, D), 5, 1.5)
+    w = _rand((D,), 6, 0.1) + 1.0
+    x, out = ops.rmsnorm_add_parts(parts, w, 1e-6)
+    xs = parts[0].clone()
+    for q in range(1, P):
+        xs += parts[q]
+    assert torch.equal(x, xs)
+    ref = w * (xs * torch.rsqrt(xs.pow(2).mean(-1, keepdim=True) + 1e-6))
+    assert _rel(out.float(), ref) < 5e-3
+    assert torch.equal(out, ops.rmsnorm(xs, w, 1e-6)) or _rel(out.float(), ops.rmsnorm(xs, w, 1e-6).float()) < 8e-3
+
+
+def test_prefill_split_k_route_matches_the_unsplit_one():
+    """Skinny prompts send o_proj / down_proj through split-K + hk_rmsnorm_add_parts: same logits and hidden states as the
+    unsplit route to fp32 summation-order noise (bf16 rounding of the normalised stream can flip a last bit)."""
+    from hawkeye_amd.config import LlmConfig
+    from hawkeye_amd.llm import LlamaPrefill
+    cfg = LlmConfig(hidden_size=1024, num_hidden_layers=3, num_attention_heads=8, intermediate_size=4096, vocab_size=512,
+                    max_position_embeddings=512)
+    B, S = 1, 200
+    src = torch.randint(0, cfg.vocab_size, (B, S), device=DEV)
+    outs = []
+    for sk in (1, 4):
+        m = LlamaPrefill(cfg, DEV).init_random(3)
+        m.split_k_for = lambda M, N, K, sk=sk: sk if (K // 64) % sk == 0 else 1
+        r = m.prefill(src=src)
+        outs.append((r["logits"].clone(), r["hidden"].float().clone()))
+        if sk > 1:
+            assert any(name == "hk_rmsnorm_add_parts" for _, _, name in next(iter(m.plans.values())).steps)
+    assert _rel(outs[1][0], outs[0][0]) < 2e-2 and _rel(outs[1][1], outs[0][1]) < 2e-2
+
+
 def test_rope_matches_reference_formula():
     from oracle import llama_prefill_oracle as LO
     B, S, H, hd = 2, 37, 3, 128

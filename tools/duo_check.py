@@ -160,7 +160,7 @@ if __name__ == "__main__":
     if "time" in what:
         time_all()
     if "llm" in what:
-        time_llm()
+        time_llm(int(os.environ.get("LLM_M", 2816)))
     if "digest" in what:
         digest()
     if "pp" in what:
