@@ -1534,10 +1534,16 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
     static const int r192 = getenv("HK_GEMM_192") ? atoi(getenv("HK_GEMM_192")) : 1;
     // rows a tile height pads M to: 192-row tiles waste less on skinny problems (M = 352, a B = 1 prompt: 384 rows instead of 512)
     auto padded = [](int M_, int bm) { return (M_ + bm - 1) / bm * bm; };
+    static const int mid_stages = getenv("HK_GEMM_MID_STAGES") ? atoi(getenv("HK_GEMM_MID_STAGES")) : 3;
     auto small = [&](const GemmParams& q) {
         if (mid_window(q.M)) {   // also the tail rows of a split persistent launch
             const long t192 = (long)((q.M + 191) / 192) * ((d->N + 127) / 128);
-            if (r192 != 0 && padded(q.M, 192) < padded(q.M, 256) && t192 <= 256) return launch<192, 128, 4, 2, 2>(q, s);
+            // (three stages, 120 KB: with weights that arrive cold from HBM -- the LLM's, read once per pass -- a two-deep ring
+            // stalls on every K-tile: M = 352 qkv, cold weights, 70.4 -> 56.3 us; tools/cold_weights.py)
+            if (r192 != 0 && padded(q.M, 192) < padded(q.M, 256) && t192 <= 256) return launch<192, 128, 4, 2, 3>(q, s);
+            // three stages (144 KB) here too: whole calls, HK_GEMM_MID_STAGES=2 / 3 interleaved on one box -- B = 2 T = 16 9.10 -> 8.82 ms,
+            // B = 3 T = 12 8.69 -> 8.47, B = 4 T = 8 8.11 -> 7.83; B = 1 calls and the rest within 0.3 %
+            if (mid_stages == 3) return launch<256, 128, 4, 2, 3>(q, s);
             return launch<256, 128, 4, 2, 2>(q, s);
         }
         const long t128 = (long)((q.M + 127) / 128) * ((q.N + 127) / 128);
@@ -1581,7 +1587,8 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
         const long tmid = (long)((d->M + 255) / 256) * ((d->N + 127) / 128) * p.ksplit;
         if (mid != 0 && tmid >= 160 && tmid <= 256) {
             const long t192 = (long)((d->M + 191) / 192) * ((d->N + 127) / 128) * p.ksplit;
-            if (r192 != 0 && padded(d->M, 192) < padded(d->M, 256) && t192 <= 256) return launch<192, 128, 4, 2, 2>(p, s);
+            if (r192 != 0 && padded(d->M, 192) < padded(d->M, 256) && t192 <= 256) return launch<192, 128, 4, 2, 3>(p, s);
+            if (mid_stages == 3) return launch<256, 128, 4, 2, 3>(p, s);
             return launch<256, 128, 4, 2, 2>(p, s);
         }
         if (t128 >= 384) return launch<128, 128, 2, 2, 2>(p, s);
@@ -1604,6 +1611,8 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
         return epi == 0 ? launch_pp<0, 3>(p, s) : epi == 1 ? launch_pp<1, 3>(p, s) : launch_pp<5, 3>(p, s);
     // HK_GEMM_192=3 (experiments): the multi-stage kernel on 192x128 tiles
     if (r192 == 3 && d->split_k <= 1) return launch<192, 128, 4, 2, 2>(p, s);
+    if (r192 == 4 && d->split_k <= 1) return launch<192, 128, 4, 2, 3>(p, s);
+    if (r192 == 5 && d->split_k <= 1) return launch<192, 128, 4, 2, 4>(p, s);
     if (mid_window(d->M)) return small(p);
     if (variant != 0 && tiles256 >= pp_min && d->N % 256 == 0 && off32) {
         // Tail balance: the persistent kernel gives each of the 256 CUs floor or ceil(tiles / 256) tiles, so a

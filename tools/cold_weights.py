@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hawkeye_amd import ops
 DEV = "cuda:0"
 torch.set_grad_enabled(False)
-M = 2816
+M = int(os.environ.get('LLM_M', 2816))
 def timeit(fns, iters):
     for f in fns: f()
     torch.cuda.synchronize()
