@@ -1613,6 +1613,7 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
     if (r192 == 3 && d->split_k <= 1) return launch<192, 128, 4, 2, 2>(p, s);
     if (r192 == 4 && d->split_k <= 1) return launch<192, 128, 4, 2, 3>(p, s);
     if (r192 == 5 && d->split_k <= 1) return launch<192, 128, 4, 2, 4>(p, s);
+    if (r192 == 6 && d->split_k <= 1) return launch<192, 192, 4, 2, 3>(p, s);
     if (mid_window(d->M)) return small(p);
     if (variant != 0 && tiles256 >= pp_min && d->N % 256 == 0 && off32) {
         // Tail balance: the persistent kernel gives each of the 256 CUs floor or ceil(tiles / 256) tiles, so a
@@ -1657,6 +1658,13 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
         // One partial round of 256-row tiles (tiles256 < CUs) that 192-row tiles still cover in one round: the round then
         // takes 3/4 of the time on more of the chip (prefill o_proj / down_proj at M = 2816: 176 -> 240 workgroups).
         // HK_GEMM_192=0 turns the rule off (A/B aid).  Instantiated for the epilogue kinds that meet such shapes.
+        // Skinny gate | up of the LLM (SwiGLU epilogue: weights always arrive cold, each layer's are read once per pass): 192 x 192 tiles
+        // of the multi-stage kernel with THREE stages when they make more workgroups in one round than the 192 x 256 tiles below
+        // (M = 352, N = 22016: 230 vs 172).  Cold weights (tools/cold_weights.py): 95.9 -> 81.2 us; with hot ones it loses (74 -> 80),
+        // so the hot-weight epilogue kinds keep the persistent kernel.
+        const long t192sq = (long)((d->M + 191) / 192) * ((d->N + 191) / 192);
+        if (r192 != 0 && tail.M == 0 && epi == 5 && tiles256 < ncu && padded(d->M, 192) < padded(d->M, 256) && t192sq > tiles192 && t192sq <= ncu)
+            return launch<192, 192, 4, 2, 3>(p, s);
         // ... or cover it with as many workgroups and fewer padded rows (M = 352, gate | up: 172 workgroups either way, 384 rows)
         if (r192 != 0 && tail.M == 0 && !use_duo && tiles256 < ncu && tiles192 <= ncu && (epi == 0 || epi == 1 || epi == 5) &&
             (tiles192 > tiles256 || (tiles192 == tiles256 && padded(d->M, 192) < padded(d->M, 256)))) {

@@ -98,7 +98,9 @@ def test_gemm_192_row_tile_shapes(M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K,bias", [(1280, 8192, 256, False), (1300, 8192, 128, True), (100, 512, 64, True),
-                                        (2816, 22016, 128, False), (257, 1056, 192, False), (66000, 512, 64, True)])
+                                        (2816, 22016, 128, False), (257, 1056, 192, False), (66000, 512, 64, True),
+                                        (352, 22016, 128, False), (330, 24576, 64, True),     # skinny prompts: 192x192 tiles, three stages
+                                        (704, 22016, 64, False)])                             # ... and the persistent 192x256 tile
 def test_gemm_swiglu_epilogue_on_interleaved_gate_up_rows(M, N, K, bias):
     """HK_ACT_SWIGLU (modeling_llama.py:143-155): W rows interleaved (gate_0, up_0, ...), C [M, N/2] = silu(gate) * up, on the
     persistent kernel (whole and partial tiles, with and without its tail launch) and on the multi-stage kernel; vs fp32."""
