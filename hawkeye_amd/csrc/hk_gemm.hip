@@ -1609,11 +1609,10 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
     // HK_GEMM_192=2 (experiments): the 192-row tile for every launch it covers in one round, before the other small-shape rules
     if (r192 == 2 && variant != 0 && d->N % 256 == 0 && off32 && tiles192 <= 256 && (epi == 0 || epi == 1 || epi == 5))
         return epi == 0 ? launch_pp<0, 3>(p, s) : epi == 1 ? launch_pp<1, 3>(p, s) : launch_pp<5, 3>(p, s);
-    // HK_GEMM_192=3 (experiments): the multi-stage kernel on 192x128 tiles
-    if (r192 == 3 && d->split_k <= 1) return launch<192, 128, 4, 2, 2>(p, s);
+    // HK_GEMM_192=4 / 6 / 7 (experiments): one three-stage multi-stage tile for every launch -- 192x128, 192x192, 256x128
     if (r192 == 4 && d->split_k <= 1) return launch<192, 128, 4, 2, 3>(p, s);
-    if (r192 == 5 && d->split_k <= 1) return launch<192, 128, 4, 2, 4>(p, s);
     if (r192 == 6 && d->split_k <= 1) return launch<192, 192, 4, 2, 3>(p, s);
+    if (r192 == 7 && d->split_k <= 1) return launch<256, 128, 4, 2, 3>(p, s);
     if (mid_window(d->M)) return small(p);
     if (variant != 0 && tiles256 >= pp_min && d->N % 256 == 0 && off32) {
         // Tail balance: the persistent kernel gives each of the 256 CUs floor or ceil(tiles / 256) tiles, so a
