@@ -148,3 +148,15 @@ def test_integration_md_ctypes_stub_matches_the_descriptor():
     assert [(n, getattr(Gemm, n).offset) for n, _ in Gemm._fields_] == \
            [(n, getattr(L.HkGemmDesc, n).offset) for n, _ in L.HkGemmDesc._fields_]
     assert re.search(r"split_k.*split_stride", block)
+
+
+def test_prefill_split_k_rule_for_skinny_prompts():
+    """LlamaPrefill.split_k_for (host logic, no GPU): o_proj / down_proj of a B = 1 / 2 prompt are split over K so that the
+    slices make at most one round of 256x128 tiles; the Cfg4 batch (B = 8) and anything wider stay unsplit."""
+    from hawkeye_amd.llm import LlamaPrefill
+    f = LlamaPrefill.split_k_for
+    assert f(352, 4096, 4096) == 4 and f(352, 4096, 11008) == 4          # 2 x 32 tiles x 4 slices = 256 workgroups
+    assert f(704, 4096, 4096) == 2 and f(704, 4096, 11008) == 2
+    assert f(2816, 4096, 4096) == 1 and f(2816, 4096, 11008) == 1
+    assert f(352, 4096, 64 * 20) == 1                                     # slices shorter than 16 K-tiles are not worth it
+    assert f(352, 4096, 64 * 34) == 2                                     # 34 K-tiles: 4 does not divide, 2 does
