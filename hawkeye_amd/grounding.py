@@ -7,7 +7,7 @@ segment.  Turn k+1 of an example depends on turn k's answer, but examples are in
 
   * `RecursiveGroundingBatcher` advances many examples together: one "wave" = the next turn of every example that is
     still active, cut into micro-batches of up to `micro_batch` clips -> ONE encode_frames call each (B = 8..32
-    instead of 1: 475 clips/s at micro-batches of 32 against 182.8 one clip per call, profiles/r02_cfg3_grounding.json);
+    instead of 1: 500.6 clips/s at micro-batches of 32 against 191.3 one clip per call, profiles/r03_cfg3_grounding.json);
   * frames travel as uint8 [B,T,H,W,3] (4x fewer bytes than the fp32 clip; /255, mean, std happen inside the patch
     gather, hk_patchify_u8) through two PINNED host buffers and two device buffers: while the GPU encodes micro-batch
     k, the host decodes micro-batch k+1 into the other pinned buffer and a side stream copies it over;
