@@ -1657,16 +1657,28 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
         // One partial round of 256-row tiles (tiles256 < CUs) that 192-row tiles still cover in one round: the round then
         // takes 3/4 of the time on more of the chip (prefill o_proj / down_proj at M = 2816: 176 -> 240 workgroups).
         // HK_GEMM_192=0 turns the rule off (A/B aid).  Instantiated for the epilogue kinds that meet such shapes.
-        // Skinny gate | up of the LLM (SwiGLU epilogue: weights always arrive cold, each layer's are read once per pass): 192 x 192 tiles
-        // of the multi-stage kernel with THREE stages when they make more workgroups in one round than the 192 x 256 tiles below
-        // (M = 352, N = 22016: 230 vs 172).  Cold weights (tools/cold_weights.py): 95.9 -> 81.2 us; with hot ones it loses (74 -> 80),
-        // so the hot-weight epilogue kinds keep the persistent kernel.
+        // Weight matrices of 64 MB and more (the LLM's qkv / gate | up / down projections) cannot stay in the 32 MB of L2 and are read
+        // once per pass: they arrive COLD from HBM, and the persistent kernel's two-K-tile ring (all 160 KB of LDS) stalls on them --
+        // +7...+22 % against a re-used buffer (tools/cold_weights.py).  While the problem is a few rounds, 192 x 192 tiles of the
+        // multi-stage kernel with THREE stages win whenever they need fewer (shorter) rounds: a round of them measured 72-81 us
+        // cold against 90-101 us for a round of the persistent kernel, hence the factor.  M = 352 gate | up 95.9 -> 81.2 us,
+        // M = 704 qkv 95.4 -> 83.7, gate | up 181.6 -> 153.9, M = 1408 qkv 181.0 -> 153.2; M = 1056 / 2112 / 2816 keep the persistent
+        // kernel (fewer rounds there).  With weights that stay in cache the persistent kernel wins (74 vs 80 us): ViT / Q-Former
+        // weights are at most 8 MB.
         const long t192sq = (long)((d->M + 191) / 192) * ((d->N + 191) / 192);
-        if (r192 != 0 && tail.M == 0 && epi == 5 && tiles256 < ncu && padded(d->M, 192) < padded(d->M, 256) && t192sq > tiles192 && t192sq <= ncu)
+        const bool cold_w = (int64_t)d->N * d->K * 2 >= (64LL << 20);
+        if (r192 != 0 && tail.M == 0 && !use_duo && cold_w && (epi == 0 || epi == 5) &&
+            0.76 * (double)((t192sq + ncu - 1) / ncu) < (double)((tiles256 + ncu - 1) / ncu) - 0.05)
             return launch<192, 192, 4, 2, 3>(p, s);
         // ... or cover it with as many workgroups and fewer padded rows (M = 352, gate | up: 172 workgroups either way, 384 rows)
         if (r192 != 0 && tail.M == 0 && !use_duo && tiles256 < ncu && tiles192 <= ncu && (epi == 0 || epi == 1 || epi == 5) &&
             (tiles192 > tiles256 || (tiles192 == tiles256 && padded(d->M, 192) < padded(d->M, 256)))) {
+            return epi == 0 ? launch_pp<0, 3>(p, s) : epi == 1 ? launch_pp<1, 3>(p, s) : launch_pp<5, 3>(p, s);
+        }
+        // ... or a tile count just past a whole number of rounds (M = 704, gate | up: 258 tiles of 256 rows = two rounds for 2 tiles;
+        // 344 tiles of 192 rows are two SHORTER rounds): rounds x relative tile time, a 192-row round measured at ~0.8 of a 256-row one
+        if (r192 != 0 && tail.M == 0 && !use_duo && (epi == 0 || epi == 1 || epi == 5) && tiles256 < 2 * ncu &&
+            0.8 * (double)((tiles192 + ncu - 1) / ncu) < (double)((tiles256 + ncu - 1) / ncu) - 0.05) {
             return epi == 0 ? launch_pp<0, 3>(p, s) : epi == 1 ? launch_pp<1, 3>(p, s) : launch_pp<5, 3>(p, s);
         }
         int rc;
