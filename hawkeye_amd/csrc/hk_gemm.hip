@@ -1671,9 +1671,9 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
             0.76 * (double)((t192sq + ncu - 1) / ncu) < (double)((tiles256 + ncu - 1) / ncu) - 0.05)
             return launch<192, 192, 4, 2, 3>(p, s);
         // ... or cover it with as many workgroups and fewer padded rows (M = 352, gate | up: 172 workgroups either way, 384 rows)
-        if (r192 != 0 && tail.M == 0 && !use_duo && tiles256 < ncu && tiles192 <= ncu && (epi == 0 || epi == 1 || epi == 5) &&
+        if (r192 != 0 && tail.M == 0 && !use_duo && tiles256 < ncu && tiles192 <= ncu && (epi == 0 || epi == 1 || epi == 5 || epi == 3) &&
             (tiles192 > tiles256 || (tiles192 == tiles256 && padded(d->M, 192) < padded(d->M, 256)))) {
-            return epi == 0 ? launch_pp<0, 3>(p, s) : epi == 1 ? launch_pp<1, 3>(p, s) : launch_pp<5, 3>(p, s);
+            return epi == 0 ? launch_pp<0, 3>(p, s) : epi == 1 ? launch_pp<1, 3>(p, s) : epi == 3 ? launch_pp<3, 3>(p, s) : launch_pp<5, 3>(p, s);
         }
         // ... or a tile count just past a whole number of rounds (M = 704, gate | up: 258 tiles of 256 rows = two rounds for 2 tiles;
         // 344 tiles of 192 rows are two SHORTER rounds): rounds x relative tile time, a 192-row round measured at ~0.8 of a 256-row one

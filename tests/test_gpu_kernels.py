@@ -177,7 +177,9 @@ def test_gemm_split_tail_rows_match_a_plain_launch(M, N, K):
 @pytest.mark.parametrize("M,N,K,act", [(512, 768, 1024, "none"), (66000, 1024, 1024, "gelu"), (300, 272, 128, "gelu"),
                                          (100352 // 4 + 7, 3072, 1024, "none"),
                                          # one round of 256x128 tiles (B = 1 calls): qkv at T = 12 (240 tiles), fc1 at T = 8 (224)
-                                         (2352, 3072, 1024, "none"), (1568 - 5, 4096, 1024, "gelu")])
+                                         (2352, 3072, 1024, "none"), (1568 - 5, 4096, 1024, "gelu"),
+                                         # the persistent kernel's 192 x 256 tile (fc1 at B = 1, T = 12: 208 tiles; ragged last row tile)
+                                         (2353, 4096, 1024, "gelu"), (2300, 4096, 256, "none")])
 def test_gemm_with_folded_layernorm(M, N, K, act):
     """hk_row_stats + row_stats/col_c epilogue == LayerNorm -> Linear (-> GELU) in fp32 (vit.py:125-127), on a residual
     stream with a per-row offset and outlier channels (the mean term must cancel, not merely be small)."""
