@@ -314,7 +314,9 @@ class HipEncoderEngine:
         if os.environ.get("HK_GEMM_MID", "1") != "0":
             tmid = -(-M // 256) * -(-N // 128)
             s = min(cap, 256 // max(tmid, 1), kt // 16)
-            if s >= 3 and tmid * s >= 160:
+            # (two slices too since the 256x128 tile runs three stages: HK_SPLIT_K_VIT_MIN=3 / 2 interleaved on one box, B = 1 T = 14
+            # 5.44 -> 5.35 ms, T = 16 5.76 -> 5.68, B = 2 T = 8 5.33 -> 5.24; with the two-stage tile the 2-slice case had measured +1 %)
+            if s >= int(os.environ.get("HK_SPLIT_K_VIT_MIN", "2")) and tmid * s >= 160:
                 return s
         t128 = -(-M // 128) * -(-N // 128)
         s = min(cap, 256 // max(t128, 1), kt // 16)
