@@ -79,7 +79,9 @@ def test_gemm_epilogues_and_row_maps():
     assert _rel(out2, ref2) < 2e-5
 
 
-@pytest.mark.parametrize("M,N,K", [(2816, 4096, 512), (2716, 4096, 320), (1400, 8192, 128)])
+@pytest.mark.parametrize("M,N,K", [(2816, 4096, 512), (2716, 4096, 320), (1400, 8192, 128),
+                                   (704, 12288, 4096), (1400, 12288, 2752),   # weights >= 64 MB, few rounds: 192x192 tiles, three stages
+                                   (352, 12288, 1024), (700, 3072, 256)])      # skinny: 192x128 tiles, three stages / persistent 192x256
 def test_gemm_192_row_tile_shapes(M, N, K):
     """One partial round of 256-row tiles that 192-row tiles cover better (prefill o_proj / down_proj: 176 -> 240
     workgroups) runs the persistent kernel's 192 x 256 instantiation: bf16-out and fp32-out-with-residual epilogues,
