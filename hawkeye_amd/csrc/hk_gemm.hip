@@ -1634,7 +1634,12 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
         tail.M = 0;
         // HK_GEMM_SPLIT_MAX: largest partial round (in tiles) that still goes to the second launch (default: under half a chip)
         static const int split_max = getenv("HK_GEMM_SPLIT_MAX") ? atoi(getenv("HK_GEMM_SPLIT_MAX")) : ncu / 2 - 1;
-        if (split && rem != 0 && rem <= split_max && tiles256 >= 2 * ncu) {
+        // HK_GEMM_SPLIT_MIN=<rounds>: fewest whole rounds a launch needs before its partial round may go to the second launch.
+        // One since round 3 (was two): proj / fc2 at B = 6, T = 16 are 296 tiles = one round plus 40 tiles, i.e. two rounds at 58 % --
+        // whole calls, HK_GEMM_SPLIT_MIN=2 / 1 interleaved on one box: B = 6 T = 16 19.97 -> 19.30 ms, B = 7 T = 16 21.96 -> 21.44,
+        // B = 7 T = 12 17.46 -> 16.78, B = 8 T = 12 18.85 -> 18.30; B = 5 / 6 T = 12, B = 10 T = 8 within +-0.5 %
+        static const int split_min = getenv("HK_GEMM_SPLIT_MIN") ? atoi(getenv("HK_GEMM_SPLIT_MIN")) : 1;
+        if (split && rem != 0 && rem <= split_max && tiles256 >= (long)split_min * ncu) {
             const int rows_main = (int)((tiles256 - rem) / nbn);   // whole tile rows inside the full rounds
             if (rows_main > 0 && rows_main < nbm) {
                 tail.m_off = rows_main * 256;
