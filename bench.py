@@ -82,6 +82,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-insitu", action="store_true", help="skip the per-kernel in-situ timing and the MFMA probe (PMC passes)")
+    ap.add_argument("--overlap-gather", action="store_true",
+                    help="all_gather of call k on RCCL's stream beside the kernels of call k + 1 (default: in line on the compute "
+                         "stream; unmeasured at N > 1 -- RCCL's workgroups then share CUs with the persistent GEMMs)")
     ap.add_argument("--force-gather", action="store_true", help="run the output all_gather even with one rank (plumbing test)")
     args = ap.parse_args()
 
@@ -122,15 +125,22 @@ def main():
     ids, mask = ids.to(dev), mask.to(dev)
     gather = (world > 1 and not args.no_gather) or args.force_gather
 
+    # --overlap-gather: the all_gather of call k runs on RCCL's stream beside the kernels of call k + 1
+    # (hawkeye_amd.dist.OutputGatherer); the last one is collected inside the timed region
+    gatherer = hdist.OutputGatherer()
+
     @torch.no_grad()
     def step():
         out, _ = model.encode_img(image, (ids, mask))
+        if gather and args.overlap_gather:
+            return gatherer.submit(out)
         if gather:
             out = hdist.gather_outputs(out)
         return out
 
     for _ in range(args.warmup):
         step()
+    gatherer.collect()
     hdist.barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -138,6 +148,7 @@ def main():
     ev0.record()
     for _ in range(args.steps):
         out = step()
+    out = gatherer.collect() if gatherer.pending is not None else out
     ev1.record()
     hdist.barrier()
     torch.cuda.synchronize()
@@ -178,7 +189,8 @@ def main():
             "config": {"workload": f"encode_img B={B}/GPU T={T} 224px Lt={Lt} (BASELINE configs[1])",
                        "clips_per_gpu": B, "frames": T, "tokens_per_clip": T * cfg.patches_per_frame,
                        "vit_blocks": cfg.run_depth, "parallelism": f"clip-sharded x{world}",
-                       "output_all_gather": bool(gather)},
+                       "output_all_gather": bool(gather),
+                       "gather_overlapped": bool(gather and args.overlap_gather)},
             "roofline": dict(step_roof, bound="mfma", step=step_roof),
             # one entry per rank, gathered over RCCL: N entries with N distinct (local_rank, device_index) = the
             # collective spanned N ranks on N GPUs
@@ -193,8 +205,8 @@ def main():
                       "vit.fc1_gelu": 2.0 * R_ * D_ * 4 * D_, "vit.fc2": 2.0 * R_ * D_ * 4 * D_,
                       "vit.patch_embed": 2.0 * R_ * cfg.patch_k * D_,
                       "qformer.cross_kv": 2.0 * R_ * D_ * 2 * cfg.qf_hidden * 6}
-            kname = {"vit.attn": "hk_attn_kernel<false, 1, 3, 1, false>", "vit.qkv": "hk_gemm_pp_kernel<3>",
-                     "vit.fc1_gelu": "hk_gemm_pp_kernel<3>", "vit.fc2": "hk_gemm_pp_kernel<4>", "vit.proj": "hk_gemm_pp_kernel<4>"}
+            kname = {"vit.attn": "hk_attn_kernel<false, 1, 3, 1, false>", "vit.qkv": "hk_gemm_pp_kernel<3, 4>",
+                     "vit.fc1_gelu": "hk_gemm_pp_kernel<3, 4>", "vit.fc2": "hk_gemm_pp_kernel<4, 4>", "vit.proj": "hk_gemm_pp_kernel<4, 4>"}
             eng = model.sync_engine()
             table = model._table(T == 1, N_, dev)
             prof = eng.profile(image, ids, mask, table, reps=3)

@@ -55,6 +55,38 @@ def gather_outputs(local: torch.Tensor, counts: List[int] = None) -> torch.Tenso
     return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
 
 
+class OutputGatherer:
+    """The same all_gather, overlapped with the NEXT call's kernels: submit(local) enqueues the collective on the
+    backend's own stream (RCCL: it starts when the compute stream reaches this point and runs beside what is
+    launched after it) and hands back the PREVIOUS call's gathered batch; collect() returns the last one.  A consumer
+    that works one call behind (a throughput loop, the grounding batcher's next micro-batch) never waits on xGMI.
+    The local output is copied first: the engine's output buffer is pooled and the next call writes it again."""
+
+    def __init__(self):
+        self.pending = None
+
+    def submit(self, local: torch.Tensor):
+        prev = self.collect()
+        if not dist.is_initialized():
+            self.pending = (None, local)
+            return prev
+        src = local.clone(memory_format=torch.contiguous_format)
+        out = torch.empty((dist.get_world_size() * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        work = dist.all_gather_into_tensor(out, src, async_op=True)
+        self.pending = (work, out)
+        return prev
+
+    def collect(self):
+        """The gathered batch of the last submit() (the current stream waits for it), or None if there is none."""
+        if self.pending is None:
+            return None
+        work, out = self.pending
+        self.pending = None
+        if work is not None:
+            work.wait()
+        return out
+
+
 def max_over_ranks(seconds: float, device) -> float:
     if not dist.is_initialized():
         return seconds

@@ -35,6 +35,13 @@ def _worker(rank, world, port, total, q):
     if total % world == 0:
         full2 = hd.gather_outputs(local)
         ok = ok and torch.equal(full2, full)
+    if total % world == 0:
+        # the overlapped form bench.py uses: submit() hands back the previous call's batch, collect() the last one
+        g = hd.OutputGatherer()
+        first = g.submit(local)
+        second = g.submit(local + 100.0)
+        last = g.collect()
+        ok = ok and first is None and torch.equal(second, full) and torch.equal(last, full + 100.0) and g.collect() is None
     t = hd.max_over_ranks(1.0 + rank, "cpu")
     seen = hd.ranks_seen("cpu")          # what bench.py reports as `ranks_seen`
     ok = ok and [(e["rank"], e["local_rank"]) for e in seen] == [(i, i) for i in range(world)]
@@ -242,3 +249,12 @@ def test_two_rank_gloo_recursive_grounding_batcher_equals_single_rank():
     want = torch.stack([single[e]["outputs"][0] for e in range(n)])
     for _, _, _, full in res:
         assert torch.equal(full, want)
+
+
+def test_output_gatherer_without_a_process_group_passes_the_local_batch_through():
+    from hawkeye_amd.dist import OutputGatherer
+    g = OutputGatherer()
+    a, b = torch.ones(2, 3), torch.zeros(2, 3)
+    assert g.submit(a) is None
+    assert g.submit(b) is a
+    assert g.collect() is b and g.collect() is None
