@@ -240,7 +240,7 @@ def main():
                   "32x32x16_random": round(ops.mfma_probe_tflops(1), 1)}
             res["roofline"]["measured_mfma_peak"] = mp
             res["roofline"]["step"] = dict(step_roof, frac_of_measured_peak=round(achieved / max(mp["16x16x32_random"], 1e-9), 4))
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU leg runs at N = 1 only (the other ranks would idle at the barrier)
             base, ref = cpu_baseline(sd, T, Lt, seed)
             res["cpu_baseline"] = base
             # the same clip through the HIP path, checked against the oracle run that was just timed
