@@ -1,0 +1,428 @@
+// Row f1 continued: the token-by-token half of `generate` that follows the prefill -- one new token per
+// sequence and step through the 32 decoder layers with the K/V cache (models/blip2/modeling_llama.py:176-231 with
+// past_key_value, :744-773; called from tasks/test.py:121-133 with do_sample=False, num_beams=1).
+//
+// With 1-16 rows every projection is a weight-streaming problem (13.2 GB of bf16 weights per token for Vicuna-7B): the
+// bound is HBM, not the matrix pipe.  hk_gemv_bf16 reads each weight row exactly once in whole 128-byte lines, keeps many
+// independent loads in flight per wave, and uses v_mfma_f32_16x16x32_bf16 only as a cheap 16-row dot-product engine
+// (rows past M are zero operands; the wasted flops are free under the memory bound).
+#include "hk_common.h"
+
+namespace {
+
+struct GemvParams {
+    const __bf16* x;
+    const __bf16* W;
+    void* out;
+    const float* res;
+    int M, N, K;
+    int64_t ldx, ldo;
+    int out_f32, act;
+};
+
+__device__ __forceinline__ float silu_mul_d(const float g, const float u) {   // the GEMM epilogue's form (hk_gemm.hip)
+    const float e = __builtin_amdgcn_exp2f(g * -1.4426950408889634f);
+    return g * __builtin_amdgcn_rcpf(1.0f + e) * u;
+}
+
+// y[m][n] = sum_k x[m][k] W[n][k].  One workgroup = 16 rows of W (one MFMA row block) x KS waves, wave w takes the K-blocks
+// [w * per, (w + 1) * per) of 64 elements.  Inside a 64-element block lane (i = lane & 15, q = lane >> 4) reads the 32
+// contiguous bytes k = 16 q .. 16 q + 15 of W row n0 + i -- four lanes cover one 128-byte line -- and the same k of x row i
+// (EXEC-masked to i < M, zero otherwise); the two 8-element halves are the A / B operands of two MFMAs (any k order works
+// for a dot product as long as both operands use the same one).  The accumulator of lane (j = lane & 15, q) is
+// y[m = j][n0 + 4 q .. 4 q + 3].  The K slices meet in LDS and are summed in wave order (deterministic).
+template <int KS>
+__global__ __launch_bounds__(KS * 64) void hk_gemv_kernel(const GemvParams p) {
+    __shared__ f32x4 red[KS][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, q = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int nblk = p.K >> 6;
+    const int per = (nblk + KS - 1) / KS;
+    const int b0 = wave * per, b1 = min(nblk, b0 + per);
+    const bool mvalid = i < p.M;
+    const __bf16* wp = p.W + (int64_t)min(n0 + i, p.N - 1) * p.K + q * 16 + (int64_t)b0 * 64;   // rows past N: a copy of the last, never stored
+    const __bf16* xp = p.x + (int64_t)(mvalid ? i : 0) * p.ldx + q * 16 + (int64_t)b0 * 64;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    constexpr int U = 4;   // K-blocks whose loads are issued together: 8 x 16 B of W per lane in flight
+    int b = b0;
+    for (; b + U <= b1; b += U) {
+        bf16x8 w[U][2], xv[U][2];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            w[u][0] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + u * 64));
+            w[u][1] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + u * 64 + 8));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            xv[u][0] = zero;
+            xv[u][1] = zero;
+            if (mvalid) {
+                xv[u][0] = *reinterpret_cast<const bf16x8*>(xp + u * 64);
+                xv[u][1] = *reinterpret_cast<const bf16x8*>(xp + u * 64 + 8);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[u][0], xv[u][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[u][1], xv[u][1], acc, 0, 0, 0);
+        }
+        wp += U * 64;
+        xp += U * 64;
+    }
+    for (; b < b1; ++b) {
+        const bf16x8 w0 = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp));
+        const bf16x8 w1 = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + 8));
+        bf16x8 x0 = zero, x1 = zero;
+        if (mvalid) {
+            x0 = *reinterpret_cast<const bf16x8*>(xp);
+            x1 = *reinterpret_cast<const bf16x8*>(xp + 8);
+        }
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, x1, acc, 0, 0, 0);
+        wp += 64;
+        xp += 64;
+    }
+    if (KS > 1) {
+        red[wave][lane] = acc;
+        __syncthreads();
+        if (wave != 0) return;
+        acc = red[0][lane];
+#pragma unroll
+        for (int s = 1; s < KS; ++s) acc += red[s][lane];
+    }
+    if (!mvalid) return;          // accumulator column j = lane & 15 is row m of x
+    const int m = i, n = n0 + 4 * q;
+    if (p.act == HK_ACT_SWIGLU) {  // interleaved (gate, up) rows of W -> out[m][n / 2], two values per lane
+        *reinterpret_cast<uint32_t*>(reinterpret_cast<__bf16*>(p.out) + (int64_t)m * p.ldo + (n >> 1)) =
+            pack_bf16x2(silu_mul_d(acc[0], acc[1]), silu_mul_d(acc[2], acc[3]));
+        return;
+    }
+    if (n + 4 > p.N) {             // last row block of an N that is not a multiple of 4 (a vocabulary of 32001): element by element
+        for (int v = 0; v < 4 && n + v < p.N; ++v) {
+            const float y = acc[v] + (p.res ? p.res[(int64_t)m * p.ldo + n + v] : 0.f);
+            if (p.out_f32) reinterpret_cast<float*>(p.out)[(int64_t)m * p.ldo + n + v] = y;
+            else reinterpret_cast<__bf16*>(p.out)[(int64_t)m * p.ldo + n + v] = (__bf16)y;
+        }
+        return;
+    }
+    if (p.res) acc += *reinterpret_cast<const f32x4*>(p.res + (int64_t)m * p.ldo + n);
+    if (p.out_f32) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + n) = acc;
+    } else {
+        u32x2 o;
+        o[0] = pack_bf16x2(acc[0], acc[1]);
+        o[1] = pack_bf16x2(acc[2], acc[3]);
+        *reinterpret_cast<u32x2*>(reinterpret_cast<__bf16*>(p.out) + (int64_t)m * p.ldo + n) = o;
+    }
+}
+
+// The new token's q / k / v (one row of the fused projection per sequence): rotary embedding on q and k at the row's
+// position (the arithmetic of hk_rope_kernel, hk_llm.hip: apply_rotary_pos_emb, modeling_llama.py:116-123), q scaled by
+// qscale into qout, k and v appended to the cache at `slot` (past_key_value concat, :201-206).
+// Thread -> 8 pair indices j of one (sequence, head).
+__global__ __launch_bounds__(256) void hk_rope_append_kernel(const __bf16* __restrict__ qkv, const float* __restrict__ cos_t,
+                                                             const float* __restrict__ sin_t, const int32_t* __restrict__ pos0,
+                                                             int pos_add, __bf16* __restrict__ qout, __bf16* __restrict__ kc,
+                                                             __bf16* __restrict__ vc, int B, int H, int hd, int slot,
+                                                             int64_t cache_rows, float qscale) {
+    const int half = hd >> 1, per_head = half >> 3;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * H * per_head) return;
+    const int j8 = idx % per_head;
+    const int head = (idx / per_head) % H;
+    const int b = idx / (per_head * H);
+    const int D = H * hd;
+    const int p = pos0[b] + pos_add;
+    const __bf16* row = qkv + (int64_t)b * 3 * D + head * hd + j8 * 8;
+    const float* cp = cos_t + (int64_t)p * half + j8 * 8;
+    const float* sp = sin_t + (int64_t)p * half + j8 * 8;
+    const int64_t crow = ((int64_t)b * cache_rows + slot) * D + head * hd + j8 * 8;
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(row + which * D);
+        const u32x4 bb = *reinterpret_cast<const u32x4*>(row + which * D + half);
+        const float sc = which == 0 ? qscale : 1.0f;
+        u32x4 oa, ob;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float x1[2] = {bf16_lo(a[k]), bf16_hi(a[k])}, x2[2] = {bf16_lo(bb[k]), bf16_hi(bb[k])};
+            float y1[2], y2[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float c = cp[2 * k + e], s = sp[2 * k + e];
+                y1[e] = (x1[e] * c - x2[e] * s) * sc;
+                y2[e] = (x2[e] * c + x1[e] * s) * sc;
+            }
+            oa[k] = pack_bf16x2(y1[0], y1[1]);
+            ob[k] = pack_bf16x2(y2[0], y2[1]);
+        }
+        __bf16* dst = which == 0 ? qout + (int64_t)b * D + head * hd + j8 * 8 : kc + crow;
+        *reinterpret_cast<u32x4*>(dst) = oa;
+        *reinterpret_cast<u32x4*>(dst + half) = ob;
+    }
+    *reinterpret_cast<u32x4*>(vc + crow) = *reinterpret_cast<const u32x4*>(row + 2 * D);
+    *reinterpret_cast<u32x4*>(vc + crow + half) = *reinterpret_cast<const u32x4*>(row + 2 * D + half);
+}
+
+// One query row per (sequence, head) against the cache: scores -> LDS, fp32 softmax over all keys (upcast as
+// modeling_llama.py:218; masked keys contribute exactly 0), then P.V.  q arrives scaled by softmax_scale * log2 e (exp2
+// domain).  A key's head row (hd bf16) is read by LPK = hd / 8 lanes, 16 bytes each; the 256 / LPK key groups of the
+// workgroup take keys g, g + NG, ...  Memory-bound: K and V of the head are streamed once.
+template <int HD>
+__global__ __launch_bounds__(256) void hk_decode_attn_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ kc,
+                                                             const __bf16* __restrict__ vc, const float* __restrict__ key_bias,
+                                                             __bf16* __restrict__ out, int H, int n_keys, int64_t cache_rows,
+                                                             int64_t bias_stride) {
+    extern __shared__ float sc[];            // [n_keys] scores, then probabilities
+    __shared__ float red[8];
+    __shared__ float obuf[4][HD];
+    constexpr int LPK = HD / 8, NG = 256 / LPK, GPW = 64 / LPK;   // lanes per key, key groups per workgroup / per wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = tid % LPK, g = tid / LPK;
+    const int head = blockIdx.x, b = blockIdx.y;
+    const int D = H * HD;
+    float qf[8];
+    {
+        const u32x4 u = *reinterpret_cast<const u32x4*>(q + (int64_t)b * D + head * HD + sub * 8);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            qf[2 * k] = bf16_lo(u[k]);
+            qf[2 * k + 1] = bf16_hi(u[k]);
+        }
+    }
+    const __bf16* kb = kc + (int64_t)b * cache_rows * D + head * HD + sub * 8;
+    const __bf16* vb = vc + (int64_t)b * cache_rows * D + head * HD + sub * 8;
+    const float* bias = key_bias ? key_bias + (int64_t)b * bias_stride : nullptr;
+    // ---- scores ----
+    constexpr int U = 4;
+    for (int k0 = g; k0 < n_keys; k0 += U * NG) {
+        u32x4 kv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int key = min(k0 + u * NG, n_keys - 1);
+            kv[u] = *reinterpret_cast<const u32x4*>(kb + (int64_t)key * D);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s += qf[2 * k] * bf16_lo(kv[u][k]) + qf[2 * k + 1] * bf16_hi(kv[u][k]);
+#pragma unroll
+            for (int o = LPK / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            const int key = k0 + u * NG;
+            if (sub == 0 && key < n_keys) sc[key] = s + (bias ? bias[key] * HK_LOG2E : 0.f);
+        }
+    }
+    __syncthreads();
+    // ---- softmax over the row ----
+    float mx = -3.0e38f;
+    for (int k = tid; k < n_keys; k += 256) mx = fmaxf(mx, sc[k]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int k = tid; k < n_keys; k += 256) {
+        const float pr = __builtin_amdgcn_exp2f(sc[k] - mx);
+        sc[k] = pr;
+        sum += pr;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    sum = (red[4] + red[5]) + (red[6] + red[7]);
+    // ---- P . V ----
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k0 = g; k0 < n_keys; k0 += U * NG) {
+        u32x4 vv[U];
+        float pr[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int key = k0 + u * NG;
+            pr[u] = key < n_keys ? sc[key] : 0.f;
+            vv[u] = *reinterpret_cast<const u32x4*>(vb + (int64_t)min(key, n_keys - 1) * D);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                acc[2 * k] += pr[u] * bf16_lo(vv[u][k]);
+                acc[2 * k + 1] += pr[u] * bf16_hi(vv[u][k]);
+            }
+    }
+    // key groups of one wave (lanes sub + LPK * t), then the four waves through LDS
+#pragma unroll
+    for (int o = LPK; o < 64; o <<= 1)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += __shfl_xor(acc[k], o, 64);
+    if (lane < LPK) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) obuf[wave][lane * 8 + k] = acc[k];
+    }
+    __syncthreads();
+    if (tid < HD / 2) {
+        const int d = tid * 2;
+        const float inv = 1.0f / sum;
+        const float o0 = ((obuf[0][d] + obuf[1][d]) + (obuf[2][d] + obuf[3][d])) * inv;
+        const float o1 = ((obuf[0][d + 1] + obuf[1][d + 1]) + (obuf[2][d + 1] + obuf[3][d + 1])) * inv;
+        *reinterpret_cast<uint32_t*>(out + (int64_t)b * D + head * HD + d) = pack_bf16x2(o0, o1);
+    }
+    (void)GPW;
+}
+
+// Greedy next token (do_sample=False, num_beams=1: tasks/test.py:525, test_recursive_grounding.py:298): index of the
+// largest logit of each row, the lowest index among equals (torch.argmax's choice).  One workgroup per row.
+__global__ __launch_bounds__(256) void hk_argmax_kernel(const float* __restrict__ logits, int64_t* __restrict__ out, int V,
+                                                        int64_t ld) {
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* row = logits + (int64_t)blockIdx.x * ld;
+    float best = -3.4e38f;
+    int idx = 0x7fffffff;
+    for (int k = tid; k < V; k += 256) {
+        const float v = row[k];
+        if (v > best || (v == best && k < idx)) {
+            best = v;
+            idx = k;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(idx, o, 64);
+        if (ov > best || (ov == best && oi < idx)) {
+            best = ov;
+            idx = oi;
+        }
+    }
+    if (lane == 0) {
+        bv[wave] = best;
+        bi[wave] = idx;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (bv[w] > best || (bv[w] == best && bi[w] < idx)) {
+                best = bv[w];
+                idx = bi[w];
+            }
+        out[blockIdx.x] = idx == 0x7fffffff ? 0 : idx;
+    }
+}
+
+}  // namespace
+
+extern "C" int hk_gemv_bf16(const hk_gemv_desc* d, void* stream) {
+    HK_REQUIRE(d && d->x && d->W && d->out, "hk_gemv_bf16: null pointer");
+    HK_REQUIRE(d->M >= 1 && d->M <= 16, "hk_gemv_bf16: M=%d rows (1..16: the decode step; larger batches go through hk_gemm_bf16)", d->M);
+    HK_REQUIRE(d->N > 0 && d->K > 0 && d->K % 64 == 0, "hk_gemv_bf16: N=%d must be positive, K=%d a multiple of 64", d->N, d->K);
+    HK_REQUIRE(d->act != HK_ACT_SWIGLU || d->N % 4 == 0, "hk_gemv_bf16: swiglu needs N=%d to be a multiple of 4", d->N);
+    HK_REQUIRE(d->act == HK_ACT_NONE || d->act == HK_ACT_SWIGLU, "hk_gemv_bf16: act %d not supported (none, swiglu)", d->act);
+    HK_REQUIRE(d->act != HK_ACT_SWIGLU || (d->out_f32 == 0 && d->residual == nullptr && d->ldo >= d->N / 2 && d->ldo % 2 == 0),
+               "hk_gemv_bf16: swiglu writes bf16 [M][N/2], no residual");
+    HK_REQUIRE(d->act == HK_ACT_SWIGLU || (d->ldo >= d->N && d->ldo % 4 == 0), "hk_gemv_bf16: ldo=%ld must be >= N and a multiple of 4",
+               (long)d->ldo);
+    HK_REQUIRE(d->ldx >= d->K && d->ldx % 8 == 0, "hk_gemv_bf16: ldx=%ld must be >= K and a multiple of 8", (long)d->ldx);
+    HK_REQUIRE(d->residual == nullptr || d->out_f32 != 0, "hk_gemv_bf16: a residual needs the fp32 output");
+    HK_REQUIRE(((uintptr_t)d->x | (uintptr_t)d->W | (uintptr_t)d->out | (uintptr_t)d->residual) % 16 == 0,
+               "hk_gemv_bf16: operands must be 16-byte aligned");
+    GemvParams p;
+    p.x = reinterpret_cast<const __bf16*>(d->x);
+    p.W = reinterpret_cast<const __bf16*>(d->W);
+    p.out = d->out;
+    p.res = d->residual;
+    p.M = d->M;
+    p.N = d->N;
+    p.K = d->K;
+    p.ldx = d->ldx;
+    p.ldo = d->ldo;
+    p.out_f32 = d->out_f32;
+    p.act = d->act;
+    // K slices (waves per workgroup): enough waves for ~8 per CU, at least 4 K-blocks per slice
+    const int nb = (d->N + 15) / 16, nblk = d->K / 64;
+    int ks = 1;
+    while (ks < 16 && (long)nb * ks < 2048 && nblk / (ks * 2) >= 4) ks *= 2;
+    static const int force = getenv("HK_GEMV_KS") ? atoi(getenv("HK_GEMV_KS")) : 0;   // A/B aid
+    if (force == 1 || force == 2 || force == 4 || force == 8 || force == 16) ks = force;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)nb);
+    switch (ks) {
+        case 1: hipLaunchKernelGGL((hk_gemv_kernel<1>), grid, dim3(64), 0, s, p); break;
+        case 2: hipLaunchKernelGGL((hk_gemv_kernel<2>), grid, dim3(128), 0, s, p); break;
+        case 4: hipLaunchKernelGGL((hk_gemv_kernel<4>), grid, dim3(256), 0, s, p); break;
+        case 8: hipLaunchKernelGGL((hk_gemv_kernel<8>), grid, dim3(512), 0, s, p); break;
+        default: hipLaunchKernelGGL((hk_gemv_kernel<16>), grid, dim3(1024), 0, s, p); break;
+    }
+    HK_CHECK_LAUNCH("hk_gemv_bf16");
+    return HK_OK;
+}
+
+extern "C" int hk_decode_rope_append(const void* qkv, const float* cos_table, const float* sin_table, const int32_t* pos0,
+                                     int32_t pos_add, void* q_out, void* k_cache, void* v_cache, int32_t B, int32_t H,
+                                     int32_t head_dim, int32_t slot, int64_t cache_rows, int32_t table_rows, float qscale,
+                                     void* stream) {
+    HK_REQUIRE(qkv && cos_table && sin_table && pos0 && q_out && k_cache && v_cache, "hk_decode_rope_append: null pointer");
+    HK_REQUIRE(B > 0 && H > 0 && (head_dim == 64 || head_dim == 128), "hk_decode_rope_append: bad shape B=%d H=%d head_dim=%d", B, H,
+               head_dim);
+    HK_REQUIRE(slot >= 0 && slot < cache_rows, "hk_decode_rope_append: slot %d outside the cache (%ld rows)", slot, (long)cache_rows);
+    HK_REQUIRE(pos_add >= 0 && pos_add < table_rows, "hk_decode_rope_append: position offset %d outside the rotary table (%d rows)",
+               pos_add, table_rows);
+    HK_REQUIRE(((uintptr_t)qkv | (uintptr_t)q_out | (uintptr_t)k_cache | (uintptr_t)v_cache | (uintptr_t)cos_table |
+                (uintptr_t)sin_table) % 16 == 0, "hk_decode_rope_append: operands must be 16-byte aligned");
+    const int n = B * H * (head_dim / 16);
+    hipLaunchKernelGGL(hk_rope_append_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const __bf16*>(qkv), cos_table, sin_table, pos0, pos_add, reinterpret_cast<__bf16*>(q_out),
+                       reinterpret_cast<__bf16*>(k_cache), reinterpret_cast<__bf16*>(v_cache), B, H, head_dim, slot, cache_rows,
+                       qscale);
+    HK_CHECK_LAUNCH("hk_decode_rope_append");
+    return HK_OK;
+}
+
+extern "C" int hk_decode_attn_bf16(const void* q, const void* k_cache, const void* v_cache, const float* key_bias, void* out,
+                                   int32_t B, int32_t H, int32_t head_dim, int32_t n_keys, int64_t cache_rows,
+                                   int64_t bias_stride, void* stream) {
+    HK_REQUIRE(q && k_cache && v_cache && out, "hk_decode_attn_bf16: null pointer");
+    HK_REQUIRE(B > 0 && B < 65536 && H > 0 && (head_dim == 64 || head_dim == 128), "hk_decode_attn_bf16: bad shape B=%d H=%d head_dim=%d",
+               B, H, head_dim);
+    HK_REQUIRE(n_keys >= 1 && n_keys <= cache_rows && n_keys <= 15360,
+               "hk_decode_attn_bf16: n_keys=%d must be 1..min(cache rows, 15360: the score row lives in LDS)", n_keys);
+    HK_REQUIRE(key_bias == nullptr || bias_stride >= n_keys, "hk_decode_attn_bf16: bias_stride < n_keys");
+    HK_REQUIRE(((uintptr_t)q | (uintptr_t)k_cache | (uintptr_t)v_cache | (uintptr_t)out) % 16 == 0,
+               "hk_decode_attn_bf16: operands must be 16-byte aligned");
+    const dim3 grid((unsigned)H, (unsigned)B);
+    const size_t lds = (size_t)n_keys * sizeof(float);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    static std::atomic<unsigned long long> done64{0}, done128{0};
+    if (head_dim == 128) {
+        if (lds > 48 * 1024) {
+            const hipError_t e = hk_lds_attr_once(done128, reinterpret_cast<const void*>(&hk_decode_attn_kernel<128>), 64 * 1024);
+            HK_REQUIRE(e == hipSuccess, "hk_decode_attn_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        }
+        hipLaunchKernelGGL((hk_decode_attn_kernel<128>), grid, dim3(256), lds, s, reinterpret_cast<const __bf16*>(q),
+                           reinterpret_cast<const __bf16*>(k_cache), reinterpret_cast<const __bf16*>(v_cache), key_bias,
+                           reinterpret_cast<__bf16*>(out), H, n_keys, cache_rows, bias_stride);
+    } else {
+        if (lds > 48 * 1024) {
+            const hipError_t e = hk_lds_attr_once(done64, reinterpret_cast<const void*>(&hk_decode_attn_kernel<64>), 64 * 1024);
+            HK_REQUIRE(e == hipSuccess, "hk_decode_attn_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        }
+        hipLaunchKernelGGL((hk_decode_attn_kernel<64>), grid, dim3(256), lds, s, reinterpret_cast<const __bf16*>(q),
+                           reinterpret_cast<const __bf16*>(k_cache), reinterpret_cast<const __bf16*>(v_cache), key_bias,
+                           reinterpret_cast<__bf16*>(out), H, n_keys, cache_rows, bias_stride);
+    }
+    HK_CHECK_LAUNCH("hk_decode_attn_bf16");
+    return HK_OK;
+}
+
+extern "C" int hk_argmax_f32(const float* logits, int64_t* out, int32_t rows, int32_t V, int64_t ld, void* stream) {
+    HK_REQUIRE(logits && out && rows > 0 && V > 0 && ld >= V, "hk_argmax_f32: bad arguments rows=%d V=%d", rows, V);
+    hipLaunchKernelGGL(hk_argmax_kernel, dim3((unsigned)rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), logits, out, V, ld);
+    HK_CHECK_LAUNCH("hk_argmax_f32");
+    return HK_OK;
+}

@@ -36,6 +36,14 @@ class HkGemmDesc(C.Structure):
     ]
 
 
+class HkGemvDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("W", C.c_void_p), ("out", C.c_void_p), ("residual", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("out_f32", C.c_int32),
+        ("ldx", C.c_int64), ("ldo", C.c_int64), ("act", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
 class HkAttnDesc(C.Structure):
     _fields_ = [
         ("Q", C.c_void_p), ("K", C.c_void_p), ("V", C.c_void_p), ("O", C.c_void_p), ("key_bias", C.c_void_p),
@@ -96,6 +104,13 @@ SYMBOLS = {
     "hk_rmsnorm": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
     "hk_rope_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "hk_gemv_bf16": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "hk_decode_rope_append": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
+                                        C.c_float, C.c_void_p]),
+    "hk_decode_attn_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                      C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
+    "hk_argmax_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
     "hk_silu_mul_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "hk_rmsnorm_add_parts": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                        C.c_int32, C.c_float, C.c_void_p]),

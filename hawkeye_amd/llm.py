@@ -88,6 +88,7 @@ class LlamaPrefill:
         # descriptor sets, kept LRU and rebuilt when a buffer had to grow.
         self.pool = _Pool(self.device)
         self.plans: "OrderedDict[Tuple[int, int, bool, bool], _Plan]" = OrderedDict()   # (B, S, masked, explicit position ids)
+        self.last_ws: Dict[str, torch.Tensor] = {}
 
     def pooled_bytes(self) -> int:
         return self.pool.nbytes()
@@ -360,6 +361,7 @@ class LlamaPrefill:
                 rc = fn(*args, stream)
                 if rc != 0:
                     L.check(rc, name)
+        self.last_ws = ws       # the generator (hawkeye_amd/decode.py) copies K / V of every layer out of it
         kv = [(ws["qkv"][i].view(B, S, 3, H, hd)[:, :, 1], ws["qkv"][i].view(B, S, 3, H, hd)[:, :, 2])
               for i in range(cfg.num_hidden_layers)]
         return {"hidden": ws["xn"].view(B, S, D), "logits": ws["logits"], "kv": kv}

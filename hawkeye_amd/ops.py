@@ -349,6 +349,88 @@ def rope_(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, H: int, head_
     return qkv
 
 
+def gemv_desc(x, W, out, M, N, K, *, ldx=None, ldo=None, residual=None, out_f32=False, act="none") -> L.HkGemvDesc:
+    """Descriptor of one hk_gemv_bf16 call on raw pointers (the decode plan builds these once)."""
+    d = L.HkGemvDesc()
+    d.x, d.W, d.out, d.residual = x, W, out, residual
+    d.M, d.N, d.K, d.out_f32 = M, N, K, 1 if out_f32 else 0
+    d.act = {"none": L.HK_ACT_NONE, "swiglu": L.HK_ACT_SWIGLU}[act]
+    d.ldx = K if ldx is None else ldx
+    d.ldo = (N // 2 if act == "swiglu" else N) if ldo is None else ldo
+    d.reserved = 0
+    return d
+
+
+def gemv(x: torch.Tensor, w: torch.Tensor, *, residual: Optional[torch.Tensor] = None, out_f32: bool = False,
+         act: str = "none") -> torch.Tensor:
+    """x bf16 [M <= 16, K] . w bf16 [N, K]^T -> [M, N] (bf16, or fp32 with out_f32; + fp32 residual), or
+    [M, N/2] = silu(gate) * up for act="swiglu" on interleaved (gate, up) weight rows.  The decode step's Linear."""
+    _need(x, torch.bfloat16, "x")
+    _need(w, torch.bfloat16, "w")
+    if x.dim() != 2 or w.dim() != 2 or x.shape[1] != w.shape[1] or not x.is_contiguous() or not w.is_contiguous():
+        raise RuntimeError("gemv: x [M, K] and w [N, K] must be contiguous with equal K")
+    M, K = x.shape
+    N = w.shape[0]
+    if residual is not None:
+        _need(residual, torch.float32, "residual")
+        if tuple(residual.shape) != (M, N) or not residual.is_contiguous():
+            raise RuntimeError("gemv: residual must be contiguous fp32 [M, N]")
+    out = torch.empty((M, N // 2 if act == "swiglu" else N), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    d = gemv_desc(x.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, K, residual=_ptr(residual), out_f32=out_f32, act=act)
+    L.check(L.load().hk_gemv_bf16(C.byref(d), _stream()), "hk_gemv_bf16")
+    return out
+
+
+def decode_rope_append(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, pos0: torch.Tensor, pos_add: int,
+                       k_cache: torch.Tensor, v_cache: torch.Tensor, slot: int, H: int, head_dim: int, q_scale: float) -> torch.Tensor:
+    """qkv bf16 [B, 3*H*hd] of the new token -> q (rotary at pos0[b] + pos_add, scaled) bf16 [B, H*hd]; rotary k and v written to
+    row `slot` of k_cache / v_cache bf16 [B, rows, H*hd]."""
+    _need(qkv, torch.bfloat16, "qkv")
+    _need(pos0, torch.int32, "pos0")
+    _need(k_cache, torch.bfloat16, "k_cache")
+    _need(v_cache, torch.bfloat16, "v_cache")
+    B, D = qkv.shape[0], H * head_dim
+    if tuple(qkv.shape) != (B, 3 * D) or not qkv.is_contiguous() or k_cache.shape != v_cache.shape or k_cache.dim() != 3 \
+            or k_cache.shape[0] != B or k_cache.shape[2] != D or not k_cache.is_contiguous() or not v_cache.is_contiguous():
+        raise RuntimeError("decode_rope_append: qkv [B, 3*H*hd], caches contiguous [B, rows, H*hd]")
+    if pos0.numel() != B or int(pos0.min()) < 0 or int(pos0.max()) + pos_add >= cos.shape[0]:
+        raise RuntimeError("decode_rope_append: positions outside the rotary table")
+    q = torch.empty((B, D), dtype=torch.bfloat16, device=qkv.device)
+    L.check(L.load().hk_decode_rope_append(qkv.data_ptr(), cos.data_ptr(), sin.data_ptr(), pos0.data_ptr(), pos_add, q.data_ptr(),
+                                           k_cache.data_ptr(), v_cache.data_ptr(), B, H, head_dim, slot, k_cache.shape[1],
+                                           cos.shape[0], q_scale, _stream()), "hk_decode_rope_append")
+    return q
+
+
+def decode_attn(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, n_keys: int, H: int, head_dim: int,
+                key_bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One query row per (sequence, head) over cache rows [0, n_keys): bf16 [B, H*hd]."""
+    _need(q, torch.bfloat16, "q")
+    _need(k_cache, torch.bfloat16, "k_cache")
+    _need(v_cache, torch.bfloat16, "v_cache")
+    B = q.shape[0]
+    if key_bias is not None:
+        _need(key_bias, torch.float32, "key_bias")
+        if key_bias.dim() != 2 or key_bias.shape[0] != B or key_bias.stride(1) != 1:
+            raise RuntimeError("decode_attn: key_bias must be fp32 [B, >= n_keys]")
+    out = torch.empty_like(q)
+    L.check(L.load().hk_decode_attn_bf16(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), _ptr(key_bias), out.data_ptr(), B, H,
+                                         head_dim, n_keys, k_cache.shape[1], 0 if key_bias is None else key_bias.stride(0),
+                                         _stream()), "hk_decode_attn_bf16")
+    return out
+
+
+def argmax(logits: torch.Tensor) -> torch.Tensor:
+    """fp32 [rows, V] -> int64 [rows], the lowest index of the largest value."""
+    _need(logits, torch.float32, "logits")
+    if logits.dim() != 2 or logits.stride(1) != 1:
+        raise RuntimeError("argmax: logits must be fp32 [rows, V] with unit column stride")
+    out = torch.empty((logits.shape[0],), dtype=torch.int64, device=logits.device)
+    L.check(L.load().hk_argmax_f32(logits.data_ptr(), out.data_ptr(), logits.shape[0], logits.shape[1], logits.stride(0), _stream()),
+            "hk_argmax_f32")
+    return out
+
+
 def silu_mul(gate_up: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """gate_up bf16 [rows, 2*I] (gate | up) -> silu(gate) * up, bf16 [rows, I]."""
     _need(gate_up, torch.bfloat16, "gate_up")

@@ -204,6 +204,48 @@ int hk_rope_bf16(void* qkv, const float* cos_table, const float* sin_table, cons
                  int64_t rows, int32_t H, int32_t head_dim, int32_t seq_len, int32_t table_rows, float q_scale,
                  void* stream);
 
+/* ---- decode: one new token per sequence and step (row f1 continued) --------------------------------------------------
+ * What `generate` runs after the prefill (tasks/test.py:121-133, test_recursive_grounding.py:122-134 with do_sample=False,
+ * num_beams=1): LlamaForCausalLM.forward on ONE token per sequence with past_key_values (modeling_llama.py:176-231,
+ * 482-611, 744-773).  With 1-16 rows every projection streams its weights once: these entries are HBM-bound. */
+
+/* y[M, N] = x[M, K] . W[N, K]^T for M <= 16 rows (nn.Linear without bias: q/k/v, o_proj, gate/up, down_proj, lm_head;
+ * modeling_llama.py:134-140, 160-163, 622).  x bf16 (row stride ldx), W bf16 row-major; out bf16 or fp32 (row stride ldo);
+ * residual fp32 with out's layout or NULL, added before the store (may alias out: the residual stream, :297-307);
+ * act HK_ACT_SWIGLU: W rows interleaved (gate_0, up_0, ...) and out[M, N/2] = silu(gate) * up in bf16, as hk_gemm_bf16. */
+typedef struct hk_gemv_desc {
+    const void* x;
+    const void* W;
+    void* out;
+    const float* residual;
+    int32_t M, N, K;
+    int32_t out_f32;
+    int64_t ldx, ldo;
+    int32_t act;
+    int32_t reserved;      /* 0 */
+} hk_gemv_desc;
+int hk_gemv_bf16(const hk_gemv_desc* d, void* stream);
+
+/* The new token's fused q|k|v row per sequence (bf16 [B, 3*H*head_dim]): rotary embedding on q and k at position
+ * pos0[b] + pos_add (apply_rotary_pos_emb, modeling_llama.py:116-123; the position of generate's new token is
+ * cumsum(attention_mask)[-1] - 1, :751-756), q * q_scale -> q_out bf16 [B, H*head_dim], k and v -> row `slot` of the caches
+ * (bf16 [B, cache_rows, H*head_dim]; the torch.cat of past_key_value, :201-206). */
+int hk_decode_rope_append(const void* qkv, const float* cos_table, const float* sin_table, const int32_t* pos0,
+                          int32_t pos_add, void* q_out, void* k_cache, void* v_cache, int32_t B, int32_t H,
+                          int32_t head_dim, int32_t slot, int64_t cache_rows, int32_t table_rows, float q_scale,
+                          void* stream);
+
+/* Attention of one query row per (sequence, head) over cache rows [0, n_keys) (modeling_llama.py:195-224 with q_len = 1:
+ * fp32 softmax, no causal term).  q as hk_decode_rope_append leaves it; key_bias fp32 [B, bias_stride] additive in the
+ * natural-log domain (0 / -10000 from hk_qformer_key_bias for left-padded batches) or NULL; out bf16 [B, H*head_dim]. */
+int hk_decode_attn_bf16(const void* q, const void* k_cache, const void* v_cache, const float* key_bias, void* out,
+                        int32_t B, int32_t H, int32_t head_dim, int32_t n_keys, int64_t cache_rows, int64_t bias_stride,
+                        void* stream);
+
+/* Greedy next token (do_sample=False, num_beams=1): out[r] = index of the largest of logits[r, 0:V] (row stride ld),
+ * the lowest index among equals. */
+int hk_argmax_f32(const float* logits, int64_t* out, int32_t rows, int32_t V, int64_t ld, void* stream);
+
 /* LlamaMLP gate (modeling_llama.py:139-140): out[rows, I] = silu(gate_up[:, :I]) * gate_up[:, I:], bf16. */
 int hk_silu_mul_bf16(const void* gate_up, void* out, int64_t rows, int32_t I, void* stream);
 

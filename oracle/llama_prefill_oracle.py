@@ -128,3 +128,24 @@ def prefill(sd, cfg, inputs_embeds, attention_mask, stages=None, position_ids=No
     last = last_valid_index(attention_mask)
     logits = F.linear(x[torch.arange(B), last], sd["lm_head.weight"])
     return x, logits, kv
+
+
+def greedy_decode(sd, cfg, inputs_embeds, attention_mask, n_tokens, forced=None):
+    """generate(do_sample=False, num_beams=1) as the eval scripts call it (tasks/test.py:121-133): the arg-max of the
+    last-position logits is appended, its embedding (embed_tokens_, :444-455) extends the sequence, the mask grows by a
+    one and positions stay cumsum(mask) - 1 (prepare_inputs_for_generation :744-773).  Restated WITHOUT a cache: by
+    causality the last row of a forward over the whole extended sequence equals the reference's one-token step with
+    past_key_values (:199-206), so this checks the cached implementations from the other side.
+    forced int64 [B, n_tokens] or None: tokens to feed instead of the arg-max.
+    Returns (logits [n_tokens, B, V] -- the logits that chose each token --, tokens [B, n_tokens])."""
+    emb, mask = inputs_embeds.float(), attention_mask.clone()
+    logits, tokens = [], []
+    for t in range(n_tokens):
+        _, lg, _ = prefill(sd, cfg, emb, mask, position_ids=generation_position_ids(mask))
+        nxt = lg.argmax(-1)
+        logits.append(lg)
+        tokens.append(nxt)
+        feed = nxt if forced is None else forced[:, t]
+        emb = torch.cat([emb, sd["model.embed_tokens.weight"][feed][:, None].float()], 1)
+        mask = torch.cat([mask, torch.ones_like(mask[:, :1])], 1)
+    return torch.stack(logits), torch.stack(tokens, 1)

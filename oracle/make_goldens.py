@@ -373,6 +373,62 @@ def llm_leftpad_goldens(outdir):
     print("wrote llm_small_leftpad.npz", tuple(out.logits.shape), pos[:, :10].tolist())
 
 
+def llm_decode_goldens(outdir, T=8):
+    """Row f1 continued, greedy generation: the reference's LlamaForCausalLM prefills a LEFT-padded batch from
+    inputs_embeds and then runs ONE token per step with past_key_values, every step's inputs built by its own
+    prepare_inputs_for_generation (modeling_llama.py:744-773) exactly as generate() drives it with do_sample=False,
+    num_beams=1 (tasks/test.py:121-133): tokens = arg-max of the last-position logits.  Recorded: the logits that chose
+    each token and the tokens."""
+    from hawkeye_amd.config import SMALL_LLM
+    spec = importlib.util.spec_from_file_location("ref_modeling_llama",
+                                                  os.path.join(REF, "models", "blip2", "modeling_llama.py"))
+    ml = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ml)
+    cfg, seed, B, S, nv = SMALL_LLM, 7, 3, 80, 16
+    lc = ml.LlamaConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
+                        num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+                        max_position_embeddings=cfg.max_position_embeddings, rms_norm_eps=cfg.rms_norm_eps,
+                        hidden_act="silu")
+    lc.num_frame_tokens = 0
+    model = ml.LlamaForCausalLM(lc).eval()
+    sd = W.make_llm_state_dict(cfg, seed)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all("rotary_emb" in k for k in missing), (missing, unexpected)
+    src, _ = W.make_prompt(cfg, B, S, nv, seed, ragged=False)
+    mask = torch.ones(B, S, dtype=torch.int64)
+    for b, n_pad in enumerate((0, 5, 41)):
+        mask[b, :n_pad] = 0
+        src[b] = torch.roll(src[b], n_pad)
+        src[b, :n_pad] = 2
+    video = W._normal("video_tokens", seed, (B * nv, cfg.hidden_size), 0.05)
+    logits, tokens = [], []
+    with torch.no_grad():
+        tok = model.model.embed_tokens_(src.clamp_min(0))
+        emb = torch.where((src >= 0)[..., None], tok, video[(-src - 1).clamp_min(0)])
+        inp = model.prepare_inputs_for_generation(None, attention_mask=mask, inputs_embeds=emb, use_cache=True)
+        out = model(inputs_embeds=inp["inputs_embeds"], attention_mask=inp["attention_mask"], position_ids=inp["position_ids"],
+                    use_cache=True, return_dict=True)
+        am, ids = mask, torch.zeros((B, 0), dtype=torch.int64)
+        for t in range(T):
+            lg = out.logits[:, -1]
+            nxt = lg.argmax(-1)
+            logits.append(lg.numpy().copy())
+            tokens.append(nxt.numpy().copy())
+            ids = torch.cat([ids, nxt[:, None]], 1)
+            am = torch.cat([am, torch.ones(B, 1, dtype=torch.int64)], 1)       # generate(): _update_model_kwargs_for_generation
+            inp = model.prepare_inputs_for_generation(ids, past_key_values=out.past_key_values, attention_mask=am,
+                                                      inputs_embeds=emb, use_cache=True)
+            assert inp["input_ids"].shape == (B, 1) and inp["position_ids"].shape == (B, 1)
+            out = model(input_ids=inp["input_ids"], attention_mask=inp["attention_mask"], position_ids=inp["position_ids"],
+                        past_key_values=inp["past_key_values"], use_cache=True, return_dict=True)
+    rec = {"B": B, "S": S, "n_video": nv, "seed": seed, "src": src.numpy(), "mask": mask.numpy(), "video": video.numpy(),
+           "step_logits": np.stack(logits), "tokens": np.stack(tokens, 1)}
+    np.savez_compressed(os.path.join(outdir, "llm_decode.npz"), **rec)
+    top2 = torch.from_numpy(rec["step_logits"]).topk(2, -1).values
+    print("wrote llm_decode.npz", rec["step_logits"].shape, "tokens", rec["tokens"].tolist(),
+          "min top-2 margin", float((top2[..., 0] - top2[..., 1]).min()))
+
+
 def _inject_masks(m, seed):
     """Train mode with reproducible randomness: every nn.Dropout / DropPath INSTANCE of the reference Q-Former gets a
     forward that applies the mask of oracle/dropout_masks.py for its site, so the reference's own module graph
@@ -474,6 +530,9 @@ def main():
         return
     if sys.argv[1:] == ["llm_leftpad"]:
         llm_leftpad_goldens(outdir)
+        return
+    if sys.argv[1:] == ["llm_decode"]:
+        llm_decode_goldens(outdir)
         return
     if sys.argv[1:] == ["train"]:
         ref_vit, ref_qf = _import_reference()

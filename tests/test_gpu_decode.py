@@ -1,0 +1,227 @@
+"""Row f1 continued -- the decode step (one new token per sequence): hk_gemv_bf16, hk_decode_rope_append,
+hk_decode_attn_bf16, hk_argmax_f32 against fp32 torch restatements of the same operator on the same inputs, and the
+greedy generation loop against the reference-module golden (tests/golden/llm_decode.npz, oracle/make_goldens.py)."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hawkeye_amd import ops, weights as W  # noqa: E402
+from hawkeye_amd.config import SMALL_LLM  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+LOG2E = 1.4426950408889634
+
+
+def _rand(shape, seed, scale=1.0, dtype=torch.float32):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(DEV).to(dtype)
+
+
+def _rel(a, ref):
+    return ((a.double() - ref.double()).abs().max() / ref.double().abs().max().clamp_min(1e-30)).item()
+
+
+# Vicuna-7B's five projection shapes, the reduced fixture's, and ragged K-slice counts (K / 64 not a multiple of the waves)
+@pytest.mark.parametrize("M,N,K", [(1, 12288, 4096), (1, 4096, 4096), (8, 4096, 11008), (3, 32000, 4096), (16, 768, 256),
+                                   (2, 320, 256), (1, 16, 64), (5, 4096, 11008 - 64), (1, 512, 192), (3, 32001, 256), (2, 30, 128)])
+@pytest.mark.parametrize("out_f32", [False, True])
+def test_gemv_matches_fp32_linear(M, N, K, out_f32):
+    x, w = _rand((M, K), 1, 1.0, torch.bfloat16), _rand((N, K), 2, 0.05, torch.bfloat16)
+    ref = x.float() @ w.float().t()
+    if N % 4:
+        # row stride kept a multiple of 4 by the caller (the generator pads its logits rows)
+        import ctypes as C
+        from hawkeye_amd import lib as L
+        ld = (N + 3) // 4 * 4
+        buf = torch.full((M, ld), 7.0, dtype=torch.float32 if out_f32 else torch.bfloat16, device=DEV)
+        d = ops.gemv_desc(x.data_ptr(), w.data_ptr(), buf.data_ptr(), M, N, K, ldo=ld, out_f32=out_f32)
+        L.check(L.load().hk_gemv_bf16(C.byref(d), torch.cuda.current_stream().cuda_stream), "hk_gemv_bf16")
+        assert _rel(buf[:, :N], ref) < (2e-5 if out_f32 else 5e-3) and bool((buf[:, N:] == 7.0).all())
+        return
+    got = ops.gemv(x, w, out_f32=out_f32)
+    assert got.shape == (M, N) and got.dtype == (torch.float32 if out_f32 else torch.bfloat16)
+    assert _rel(got, ref) < (2e-5 if out_f32 else 5e-3)
+    if out_f32:
+        res = _rand((M, N), 3)
+        got2 = ops.gemv(x, w, residual=res, out_f32=True)
+        assert _rel(got2, ref + res) < 2e-5
+        # in place on the residual stream (what the decode step does)
+        d = ops.gemv_desc(x.data_ptr(), w.data_ptr(), res.data_ptr(), M, N, K, residual=res.data_ptr(), out_f32=True)
+        import ctypes as C
+        from hawkeye_amd import lib as L
+        L.check(L.load().hk_gemv_bf16(C.byref(d), torch.cuda.current_stream().cuda_stream), "hk_gemv_bf16")
+        assert torch.equal(res, got2)
+
+
+@pytest.mark.parametrize("M,I,K", [(1, 11008, 4096), (8, 11008, 4096), (2, 512, 256)])
+def test_gemv_swiglu_matches_the_gemm_epilogue_and_fp32(M, I, K):
+    x = _rand((M, K), 4, 1.0, torch.bfloat16)
+    gate, up = _rand((I, K), 5, 0.03, torch.bfloat16), _rand((I, K), 6, 0.03, torch.bfloat16)
+    w = torch.stack([gate, up], 1).reshape(2 * I, K).contiguous()
+    got = ops.gemv(x, w, act="swiglu")
+    g, u = x.float() @ gate.float().t(), x.float() @ up.float().t()
+    ref = torch.nn.functional.silu(g) * u
+    assert got.shape == (M, I) and _rel(got, ref) < 6e-3
+    # the prefill's route for the same operator (hk_gemm_bf16, HK_ACT_SWIGLU): same values up to accumulation order
+    big = ops.linear(x, w, act="swiglu")
+    assert _rel(got, big.float()) < 6e-3
+
+
+def test_gemv_rejects_what_it_cannot_run():
+    x, w = _rand((17, 256), 1, 1.0, torch.bfloat16), _rand((64, 256), 2, 1.0, torch.bfloat16)
+    with pytest.raises(RuntimeError, match="1..16"):
+        ops.gemv(x, w)
+    with pytest.raises(RuntimeError, match="multiple of 4"):
+        ops.gemv(x[:2].contiguous(), w[:30].contiguous(), act="swiglu")
+    with pytest.raises(RuntimeError, match="of 64"):
+        ops.gemv(x[:2, :224].contiguous(), w[:, :224].contiguous())
+
+
+def _rotate_half(x):
+    h = x.shape[-1] // 2
+    return torch.cat([-x[..., h:], x[..., :h]], -1)
+
+
+@pytest.mark.parametrize("B,H,hd", [(1, 32, 128), (3, 2, 128), (2, 12, 64)])
+def test_rope_append_writes_q_and_the_cache_row(B, H, hd):
+    D, rows, slot, P = H * hd, 40, 17, 64
+    qkv = _rand((B, 3 * D), 7, 1.0, torch.bfloat16)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))
+    fr = torch.einsum("i,j->ij", torch.arange(P).float(), inv)
+    cos, sin = fr.cos().to(DEV).contiguous(), fr.sin().to(DEV).contiguous()
+    pos0 = torch.tensor([5, 11, 0][:B], dtype=torch.int32, device=DEV)
+    kc = torch.zeros((B, rows, D), dtype=torch.bfloat16, device=DEV)
+    vc = torch.zeros_like(kc)
+    qs = hd ** -0.5 * LOG2E
+    q = ops.decode_rope_append(qkv, cos, sin, pos0, 3, kc, vc, slot, H, hd, qs)
+    x = qkv.float().view(B, 3, H, hd)
+    p = (pos0 + 3).long()
+    c = torch.cat([cos[p], cos[p]], -1)[:, None]
+    s = torch.cat([sin[p], sin[p]], -1)[:, None]
+    qr = (x[:, 0] * c + _rotate_half(x[:, 0]) * s) * qs
+    kr = x[:, 1] * c + _rotate_half(x[:, 1]) * s
+    assert _rel(q.view(B, H, hd), qr) < 5e-3
+    assert _rel(kc[:, slot].view(B, H, hd), kr) < 5e-3
+    assert torch.equal(vc[:, slot], qkv[:, 2 * D:])
+    kc[:, slot] = 0
+    vc[:, slot] = 0
+    assert not kc.any() and not vc.any()        # nothing but the slot row was written
+    # same bits as the prefill's in-place kernel at the same position
+    full = qkv.clone()
+    ops.rope_(full, cos, sin, H, hd, 1, q_scale=qs, position_ids=(pos0 + 3))
+    assert torch.equal(full[:, :D], q)
+
+
+@pytest.mark.parametrize("B,H,hd,n,rows,masked", [(1, 32, 128, 353, 400, False), (3, 2, 128, 97, 128, True), (2, 12, 64, 1, 8, False),
+                                                  (2, 4, 128, 2049, 2112, True), (1, 3, 64, 130, 130, False)])
+def test_decode_attention_matches_fp32_softmax(B, H, hd, n, rows, masked):
+    D = H * hd
+    q = _rand((B, D), 8, 1.0, torch.bfloat16)
+    kc, vc = _rand((B, rows, D), 9, 1.0, torch.bfloat16), _rand((B, rows, D), 10, 1.0, torch.bfloat16)
+    bias = None
+    if masked:
+        bias = torch.zeros((B, rows), dtype=torch.float32, device=DEV)
+        for b in range(B):
+            bias[b, : (b * 37) % max(n - 1, 1)] = -10000.0     # left padding of different lengths
+    got = ops.decode_attn(q, kc, vc, n, H, hd, bias)
+    qf = q.float().view(B, H, 1, hd) / LOG2E                   # q carries softmax_scale * log2 e
+    k = kc[:, :n].float().view(B, n, H, hd).permute(0, 2, 1, 3)
+    v = vc[:, :n].float().view(B, n, H, hd).permute(0, 2, 1, 3)
+    sc = qf @ k.transpose(-1, -2)
+    if masked:
+        sc = sc + bias[:, None, None, :n]
+    ref = (torch.softmax(sc, -1) @ v).permute(0, 2, 1, 3).reshape(B, D)
+    assert _rel(got, ref) < 6e-3
+
+
+def test_argmax_lowest_index_among_equals():
+    x = _rand((5, 32000), 11)
+    x[1, 777] = 50.0
+    x[1, 31999] = 50.0
+    x[2, 0] = 60.0
+    x[3, 31999] = 70.0
+    got = ops.argmax(x)
+    assert torch.equal(got, torch.argmax(x, -1))
+    assert got[1].item() == 777 and got[2].item() == 0 and got[3].item() == 31999
+    assert torch.equal(ops.argmax(x[:, :320].contiguous()), torch.argmax(x[:, :320], -1))
+
+
+def test_generation_matches_reference_golden(golden_dir):
+    """Greedy decode of the reference's LlamaForCausalLM (prefill with inputs_embeds, then one token per step with
+    past_key_values and prepare_inputs_for_generation's position ids) on a LEFT-padded batch: per-step logits and tokens."""
+    from hawkeye_amd.llm import LlamaPrefill
+    from hawkeye_amd.decode import LlamaGenerator
+    g = np.load(os.path.join(golden_dir, "llm_decode.npz"))
+    cfg, seed = SMALL_LLM, int(g["seed"])
+    pre = LlamaPrefill(cfg, DEV).load_state_dict(W.make_llm_state_dict(cfg, seed))
+    gen = LlamaGenerator(pre)
+    src, mask = torch.from_numpy(g["src"]).to(DEV), torch.from_numpy(g["mask"]).to(DEV)
+    video = torch.from_numpy(g["video"]).to(DEV)
+    ref_logits, ref_tok = torch.from_numpy(g["step_logits"]), torch.from_numpy(g["tokens"])   # [T, B, V], [B, T]
+    T = ref_tok.shape[1]
+    # teacher-forced with the reference's tokens, so one near-tie cannot derail the steps after it
+    out = gen.generate(src=src, video=video, attention_mask=mask, max_new_tokens=T, forced_tokens=ref_tok.to(DEV),
+                       return_logits=True)
+    lg = out["logits"].cpu()
+    assert lg.shape == ref_logits.shape
+    for t in range(T):
+        a, b = lg[t].double().flatten(), ref_logits[t].double().flatten()
+        assert (a @ b / (a.norm() * b.norm())).item() > 0.9995, t
+        assert _rel(lg[t], ref_logits[t]) < 2.5e-2, t
+    # free-running greedy: same tokens wherever the reference's top-2 margin exceeds the tolerance above
+    free = gen.generate(src=src, video=video, attention_mask=mask, max_new_tokens=T)["tokens"].cpu()
+    top2 = ref_logits.topk(2, -1).values
+    margin = (top2[..., 0] - top2[..., 1]) / ref_logits.abs().amax(-1)          # [T, B]
+    for b in range(ref_tok.shape[0]):
+        for t in range(T):
+            if margin[t, b] < 5e-2:
+                break                                   # later steps depend on this near-tie
+            assert free[b, t].item() == ref_tok[b, t].item(), (b, t)
+
+
+def test_generation_stops_like_the_reference_criteria():
+    """StoppingCriteriaSub (tasks/test.py:100-109) looks at row 0's tail; eos ends a row and pads it afterwards."""
+    from hawkeye_amd.llm import LlamaPrefill
+    from hawkeye_amd.decode import LlamaGenerator
+    cfg = SMALL_LLM
+    pre = LlamaPrefill(cfg, DEV).load_state_dict(W.make_llm_state_dict(cfg, 3))
+    gen = LlamaGenerator(pre)
+    src, _ = W.make_prompt(cfg, 1, 40, 8, 3, ragged=False)
+    video = W._normal("video_tokens", 3, (8, cfg.hidden_size), 0.05)
+    full = gen.generate(src=src.to(DEV), video=video.to(DEV), max_new_tokens=12)["tokens"][0].tolist()
+    assert len(full) == 12
+    stop = full[3:5]
+    cut = gen.generate(src=src.to(DEV), video=video.to(DEV), max_new_tokens=12, stop_sequences=[stop])["tokens"][0].tolist()
+    first = next(i for i in range(1, len(full)) if full[i - 1:i + 1] == stop)
+    assert cut == full[:first + 1]
+    eos = full[2]
+    cut = gen.generate(src=src.to(DEV), video=video.to(DEV), max_new_tokens=12, eos_token_id=eos)["tokens"][0].tolist()
+    assert cut == full[:full.index(eos) + 1]
+
+
+def test_generation_kv_cache_equals_a_longer_prefill():
+    """The cache rows the decode steps append (k post-rotary, v) are what a prefill over prompt + generated tokens holds."""
+    from hawkeye_amd.llm import LlamaPrefill
+    from hawkeye_amd.decode import LlamaGenerator
+    cfg = SMALL_LLM
+    pre = LlamaPrefill(cfg, DEV).load_state_dict(W.make_llm_state_dict(cfg, 4))
+    gen = LlamaGenerator(pre)
+    src, _ = W.make_prompt(cfg, 2, 48, 8, 4, ragged=False)
+    video = W._normal("video_tokens", 4, (16, cfg.hidden_size), 0.05).to(DEV)
+    src = src.to(DEV)
+    out = gen.generate(src=src, video=video, max_new_tokens=5, return_logits=True)
+    toks = out["tokens"]
+    kc = gen.k_cache[:, :, :48 + 4].clone()                     # rows of the prompt + the 4 tokens that were fed back
+    longer = torch.cat([src, toks[:, :4]], 1)
+    ref = pre.prefill(src=longer, video=video)
+    for layer in range(cfg.num_hidden_layers):
+        k_ref = ref["kv"][layer][0].reshape(2, 52, -1)
+        assert _rel(kc[layer], k_ref) < 2e-2
+    # and the logits of the last decode step are those of the longer prefill's last position
+    assert _rel(out["logits"][4], ref["logits"]) < 2e-2

@@ -72,3 +72,27 @@ def test_llm_oracle_left_padded_batch_with_generation_position_ids(golden_dir):
     _close(logits, g["logits_last"], "logits_last")
     vk = valid[:, None, :, None].expand_as(kv[0][0])
     _close(kv[0][0][vk], torch.from_numpy(g["k0"])[vk], "k0")
+
+
+def test_llm_oracle_greedy_decode_matches_reference_generation_steps(golden_dir):
+    """Row f1 continued: the reference module's one-token steps with past_key_values (fixture llm_decode.npz) against the
+    oracle's cache-free restatement -- logits of every step and the greedy tokens."""
+    g = np.load(os.path.join(golden_dir, "llm_decode.npz"))
+    cfg, seed = SMALL_LLM, int(g["seed"])
+    sd = W.make_llm_state_dict(cfg, seed)
+    src, mask = torch.from_numpy(g["src"]), torch.from_numpy(g["mask"])
+    emb = LO.embed_splice(sd, src, torch.from_numpy(g["video"]))
+    ref_tok = torch.from_numpy(g["tokens"])
+    with torch.no_grad():
+        logits, _ = LO.greedy_decode(sd, cfg.to_dict(), emb, mask, ref_tok.shape[1], forced=ref_tok)
+        free_logits, free_tok = LO.greedy_decode(sd, cfg.to_dict(), emb, mask, 3)
+    for t in range(ref_tok.shape[1]):
+        _close(logits[t], g["step_logits"][t], f"step {t}", rel=5e-5)
+    # free-running: the same tokens while the reference's top-2 margin is not a rounding-level tie
+    top2 = torch.from_numpy(g["step_logits"]).topk(2, -1).values
+    margin = top2[..., 0] - top2[..., 1]
+    for b in range(ref_tok.shape[0]):
+        for t in range(3):
+            if margin[t, b] < 1e-3:
+                break
+            assert int(free_tok[b, t]) == int(ref_tok[b, t]), (b, t)
