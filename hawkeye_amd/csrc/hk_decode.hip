@@ -169,33 +169,72 @@ __global__ __launch_bounds__(256) void hk_rope_append_kernel(const __bf16* __res
 
 // One query row per (sequence, head) against the cache: scores -> LDS, fp32 softmax over all keys (upcast as
 // modeling_llama.py:218; masked keys contribute exactly 0), then P.V.  q arrives scaled by softmax_scale * log2 e (exp2
-// domain).  A key's head row (hd bf16) is read by LPK = hd / 8 lanes, 16 bytes each; the 256 / LPK key groups of the
-// workgroup take keys g, g + NG, ...  Memory-bound: K and V of the head are streamed once.
-template <int HD>
-__global__ __launch_bounds__(256) void hk_decode_attn_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ kc,
-                                                             const __bf16* __restrict__ vc, const float* __restrict__ key_bias,
-                                                             __bf16* __restrict__ out, int H, int n_keys, int64_t cache_rows,
-                                                             int64_t bias_stride) {
+// domain).  A key's head row (hd bf16) is read by LPK = hd / 8 lanes, 16 bytes each; the NT / LPK key groups of the
+// workgroup take keys g, g + NG, ...  Memory-bound: K and V of the head are streamed once; NT = 1024 threads keep 4x the
+// loads of one (sequence, head) in flight (B * H workgroups is all the parallelism a decode step has here).
+// FUSED: the workgroup first does hk_rope_append_kernel's work for ITS head -- it is the only reader of that head's new
+// row -- from the token's fused q|k|v row: rotary q -> LDS (rounded to bf16 as the two-launch route stores it), rotary k
+// and v -> cache row `slot`, visible to the whole workgroup after the barrier; n_keys = slot + 1.
+struct DecodeAttnParams {
+    const __bf16* q;        // !FUSED: [B][D] rotary, scaled;  FUSED: the fused q|k|v rows [B][3D]
+    __bf16* kc;
+    __bf16* vc;
+    const float* key_bias;
+    __bf16* out;
+    const float* cos_t;
+    const float* sin_t;
+    const int32_t* pos0;
+    int pos_add, slot;
+    float qscale;
+    int H, n_keys;
+    int64_t cache_rows, bias_stride;
+};
+
+template <int HD, int NT, bool FUSED>
+__global__ __launch_bounds__(NT) void hk_decode_attn_kernel(const DecodeAttnParams p) {
     extern __shared__ float sc[];            // [n_keys] scores, then probabilities
-    __shared__ float red[8];
-    __shared__ float obuf[4][HD];
-    constexpr int LPK = HD / 8, NG = 256 / LPK, GPW = 64 / LPK;   // lanes per key, key groups per workgroup / per wave
+    constexpr int NW = NT / 64;
+    __shared__ float red[2 * NW];
+    __shared__ float obuf[NW][HD];
+    __shared__ float qs[HD];
+    constexpr int LPK = HD / 8, NG = NT / LPK;   // lanes per key, key groups per workgroup
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = tid % LPK, g = tid / LPK;
     const int head = blockIdx.x, b = blockIdx.y;
-    const int D = H * HD;
+    const int D = p.H * HD;
+    const int n_keys = p.n_keys;
+    const __bf16* kb = p.kc + (int64_t)b * p.cache_rows * D + head * HD + sub * 8;
+    const __bf16* vb = p.vc + (int64_t)b * p.cache_rows * D + head * HD + sub * 8;
     float qf[8];
-    {
-        const u32x4 u = *reinterpret_cast<const u32x4*>(q + (int64_t)b * D + head * HD + sub * 8);
+    if constexpr (FUSED) {
+        constexpr int half = HD / 2;
+        const __bf16* row = p.q + (int64_t)b * 3 * D + head * HD;
+        const int64_t crow = ((int64_t)b * p.cache_rows + p.slot) * D + head * HD;
+        if (tid < half) {
+            const int pos = p.pos0[b] + p.pos_add;
+            const float c = p.cos_t[(int64_t)pos * half + tid], s = p.sin_t[(int64_t)pos * half + tid];
+            const float q1 = (float)row[tid], q2 = (float)row[tid + half];
+            const float k1 = (float)row[D + tid], k2 = (float)row[D + tid + half];
+            qs[tid] = (float)(__bf16)((q1 * c - q2 * s) * p.qscale);
+            qs[tid + half] = (float)(__bf16)((q2 * c + q1 * s) * p.qscale);
+            p.kc[crow + tid] = (__bf16)(k1 * c - k2 * s);
+            p.kc[crow + tid + half] = (__bf16)(k2 * c + k1 * s);
+        } else if (tid < half + HD / 8) {
+            const int j = (tid - half) * 8;
+            *reinterpret_cast<u32x4*>(p.vc + crow + j) = *reinterpret_cast<const u32x4*>(row + 2 * D + j);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) qf[k] = qs[sub * 8 + k];
+    } else {
+        const u32x4 u = *reinterpret_cast<const u32x4*>(p.q + (int64_t)b * D + head * HD + sub * 8);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             qf[2 * k] = bf16_lo(u[k]);
             qf[2 * k + 1] = bf16_hi(u[k]);
         }
     }
-    const __bf16* kb = kc + (int64_t)b * cache_rows * D + head * HD + sub * 8;
-    const __bf16* vb = vc + (int64_t)b * cache_rows * D + head * HD + sub * 8;
-    const float* bias = key_bias ? key_bias + (int64_t)b * bias_stride : nullptr;
+    const float* bias = p.key_bias ? p.key_bias + (int64_t)b * p.bias_stride : nullptr;
     // ---- scores ----
     constexpr int U = 4;
     for (int k0 = g; k0 < n_keys; k0 += U * NG) {
@@ -219,23 +258,27 @@ __global__ __launch_bounds__(256) void hk_decode_attn_kernel(const __bf16* __res
     __syncthreads();
     // ---- softmax over the row ----
     float mx = -3.0e38f;
-    for (int k = tid; k < n_keys; k += 256) mx = fmaxf(mx, sc[k]);
+    for (int k = tid; k < n_keys; k += NT) mx = fmaxf(mx, sc[k]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
     if (lane == 0) red[wave] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    mx = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) mx = fmaxf(mx, red[w]);
     float sum = 0.f;
-    for (int k = tid; k < n_keys; k += 256) {
+    for (int k = tid; k < n_keys; k += NT) {
         const float pr = __builtin_amdgcn_exp2f(sc[k] - mx);
         sc[k] = pr;
         sum += pr;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-    if (lane == 0) red[4 + wave] = sum;
+    if (lane == 0) red[NW + wave] = sum;
     __syncthreads();
-    sum = (red[4] + red[5]) + (red[6] + red[7]);
+    sum = red[NW];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) sum += red[NW + w];
     // ---- P . V ----
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int k0 = g; k0 < n_keys; k0 += U * NG) {
@@ -255,7 +298,7 @@ __global__ __launch_bounds__(256) void hk_decode_attn_kernel(const __bf16* __res
                 acc[2 * k + 1] += pr[u] * bf16_hi(vv[u][k]);
             }
     }
-    // key groups of one wave (lanes sub + LPK * t), then the four waves through LDS
+    // key groups of one wave (lanes sub + LPK * t), then the waves through LDS (summed in wave order)
 #pragma unroll
     for (int o = LPK; o < 64; o <<= 1)
 #pragma unroll
@@ -268,38 +311,48 @@ __global__ __launch_bounds__(256) void hk_decode_attn_kernel(const __bf16* __res
     if (tid < HD / 2) {
         const int d = tid * 2;
         const float inv = 1.0f / sum;
-        const float o0 = ((obuf[0][d] + obuf[1][d]) + (obuf[2][d] + obuf[3][d])) * inv;
-        const float o1 = ((obuf[0][d + 1] + obuf[1][d + 1]) + (obuf[2][d + 1] + obuf[3][d + 1])) * inv;
-        *reinterpret_cast<uint32_t*>(out + (int64_t)b * D + head * HD + d) = pack_bf16x2(o0, o1);
+        float o0 = obuf[0][d], o1 = obuf[0][d + 1];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) {
+            o0 += obuf[w][d];
+            o1 += obuf[w][d + 1];
+        }
+        *reinterpret_cast<uint32_t*>(p.out + (int64_t)b * D + head * HD + d) = pack_bf16x2(o0 * inv, o1 * inv);
     }
-    (void)GPW;
 }
 
 // Greedy next token (do_sample=False, num_beams=1: tasks/test.py:525, test_recursive_grounding.py:298): index of the
-// largest logit of each row, the lowest index among equals (torch.argmax's choice).  One workgroup per row.
-__global__ __launch_bounds__(256) void hk_argmax_kernel(const float* __restrict__ logits, int64_t* __restrict__ out, int V,
-                                                        int64_t ld) {
-    __shared__ float bv[4];
-    __shared__ int bi[4];
+// largest logit of each row, the lowest index among equals (torch.argmax's choice).  One workgroup of 1024 threads per row,
+// 16-byte loads where the row allows.
+__global__ __launch_bounds__(1024) void hk_argmax_kernel(const float* __restrict__ logits, int64_t* __restrict__ out, int V,
+                                                         int64_t ld) {
+    __shared__ float bv[16];
+    __shared__ int bi[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* row = logits + (int64_t)blockIdx.x * ld;
     float best = -3.4e38f;
     int idx = 0x7fffffff;
-    for (int k = tid; k < V; k += 256) {
-        const float v = row[k];
+    auto take = [&](float v, int k) {
         if (v > best || (v == best && k < idx)) {
             best = v;
             idx = k;
         }
+    };
+    const bool vec = ((uintptr_t)row & 15) == 0;
+    const int V4 = vec ? (V & ~3) : 0;
+    for (int k = tid * 4; k < V4; k += 4096) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(row + k);
+        take(v[0], k);
+        take(v[1], k + 1);
+        take(v[2], k + 2);
+        take(v[3], k + 3);
     }
+    for (int k = V4 + tid; k < V; k += 1024) take(row[k], k);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float ov = __shfl_xor(best, o, 64);
         const int oi = __shfl_xor(idx, o, 64);
-        if (ov > best || (ov == best && oi < idx)) {
-            best = ov;
-            idx = oi;
-        }
+        take(ov, oi);
     }
     if (lane == 0) {
         bv[wave] = best;
@@ -307,11 +360,7 @@ __global__ __launch_bounds__(256) void hk_argmax_kernel(const float* __restrict_
     }
     __syncthreads();
     if (tid == 0) {
-        for (int w = 1; w < 4; ++w)
-            if (bv[w] > best || (bv[w] == best && bi[w] < idx)) {
-                best = bv[w];
-                idx = bi[w];
-            }
+        for (int w = 1; w < 16; ++w) take(bv[w], bi[w]);
         out[blockIdx.x] = idx == 0x7fffffff ? 0 : idx;
     }
 }
@@ -384,45 +433,95 @@ extern "C" int hk_decode_rope_append(const void* qkv, const float* cos_table, co
     return HK_OK;
 }
 
+namespace {
+template <int HD, int NT, bool FUSED>
+int launch_decode_attn(const DecodeAttnParams& p, int B, hipStream_t s) {
+    static std::atomic<unsigned long long> done{0};
+    const size_t lds = (size_t)p.n_keys * sizeof(float);
+    if (lds > 32 * 1024) {
+        const hipError_t e = hk_lds_attr_once(done, reinterpret_cast<const void*>(&hk_decode_attn_kernel<HD, NT, FUSED>), 60 * 1024);
+        HK_REQUIRE(e == hipSuccess, "hk_decode_attn: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL((hk_decode_attn_kernel<HD, NT, FUSED>), dim3((unsigned)p.H, (unsigned)B), dim3(NT), lds, s, p);
+    return HK_OK;
+}
+template <bool FUSED>
+int dispatch_decode_attn(const DecodeAttnParams& p, int B, int head_dim, hipStream_t s) {
+    // 1024 threads per (sequence, head) unless the call already has a few workgroups per CU (HK_DECODE_ATTN_NT: A/B aid)
+    static const int force = getenv("HK_DECODE_ATTN_NT") ? atoi(getenv("HK_DECODE_ATTN_NT")) : 0;
+    const bool big = force == 1024 || (force != 256 && (long)B * p.H < 1024 && p.n_keys >= 128);
+    if (head_dim == 128) return big ? launch_decode_attn<128, 1024, FUSED>(p, B, s) : launch_decode_attn<128, 256, FUSED>(p, B, s);
+    return big ? launch_decode_attn<64, 1024, FUSED>(p, B, s) : launch_decode_attn<64, 256, FUSED>(p, B, s);
+}
+}  // namespace
+
 extern "C" int hk_decode_attn_bf16(const void* q, const void* k_cache, const void* v_cache, const float* key_bias, void* out,
                                    int32_t B, int32_t H, int32_t head_dim, int32_t n_keys, int64_t cache_rows,
                                    int64_t bias_stride, void* stream) {
     HK_REQUIRE(q && k_cache && v_cache && out, "hk_decode_attn_bf16: null pointer");
     HK_REQUIRE(B > 0 && B < 65536 && H > 0 && (head_dim == 64 || head_dim == 128), "hk_decode_attn_bf16: bad shape B=%d H=%d head_dim=%d",
                B, H, head_dim);
-    HK_REQUIRE(n_keys >= 1 && n_keys <= cache_rows && n_keys <= 15360,
-               "hk_decode_attn_bf16: n_keys=%d must be 1..min(cache rows, 15360: the score row lives in LDS)", n_keys);
+    HK_REQUIRE(n_keys >= 1 && n_keys <= cache_rows && n_keys <= 12288,
+               "hk_decode_attn_bf16: n_keys=%d must be 1..min(cache rows, 12288: the score row lives in LDS)", n_keys);
     HK_REQUIRE(key_bias == nullptr || bias_stride >= n_keys, "hk_decode_attn_bf16: bias_stride < n_keys");
     HK_REQUIRE(((uintptr_t)q | (uintptr_t)k_cache | (uintptr_t)v_cache | (uintptr_t)out) % 16 == 0,
                "hk_decode_attn_bf16: operands must be 16-byte aligned");
-    const dim3 grid((unsigned)H, (unsigned)B);
-    const size_t lds = (size_t)n_keys * sizeof(float);
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    static std::atomic<unsigned long long> done64{0}, done128{0};
-    if (head_dim == 128) {
-        if (lds > 48 * 1024) {
-            const hipError_t e = hk_lds_attr_once(done128, reinterpret_cast<const void*>(&hk_decode_attn_kernel<128>), 64 * 1024);
-            HK_REQUIRE(e == hipSuccess, "hk_decode_attn_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        }
-        hipLaunchKernelGGL((hk_decode_attn_kernel<128>), grid, dim3(256), lds, s, reinterpret_cast<const __bf16*>(q),
-                           reinterpret_cast<const __bf16*>(k_cache), reinterpret_cast<const __bf16*>(v_cache), key_bias,
-                           reinterpret_cast<__bf16*>(out), H, n_keys, cache_rows, bias_stride);
-    } else {
-        if (lds > 48 * 1024) {
-            const hipError_t e = hk_lds_attr_once(done64, reinterpret_cast<const void*>(&hk_decode_attn_kernel<64>), 64 * 1024);
-            HK_REQUIRE(e == hipSuccess, "hk_decode_attn_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        }
-        hipLaunchKernelGGL((hk_decode_attn_kernel<64>), grid, dim3(256), lds, s, reinterpret_cast<const __bf16*>(q),
-                           reinterpret_cast<const __bf16*>(k_cache), reinterpret_cast<const __bf16*>(v_cache), key_bias,
-                           reinterpret_cast<__bf16*>(out), H, n_keys, cache_rows, bias_stride);
-    }
+    DecodeAttnParams p = {};
+    p.q = reinterpret_cast<const __bf16*>(q);
+    p.kc = reinterpret_cast<__bf16*>(const_cast<void*>(k_cache));
+    p.vc = reinterpret_cast<__bf16*>(const_cast<void*>(v_cache));
+    p.key_bias = key_bias;
+    p.out = reinterpret_cast<__bf16*>(out);
+    p.H = H;
+    p.n_keys = n_keys;
+    p.cache_rows = cache_rows;
+    p.bias_stride = bias_stride;
+    const int rc = dispatch_decode_attn<false>(p, B, head_dim, reinterpret_cast<hipStream_t>(stream));
+    if (rc != HK_OK) return rc;
     HK_CHECK_LAUNCH("hk_decode_attn_bf16");
+    return HK_OK;
+}
+
+extern "C" int hk_decode_attn_rope_bf16(const void* qkv, const float* cos_table, const float* sin_table, const int32_t* pos0,
+                                        int32_t pos_add, void* k_cache, void* v_cache, const float* key_bias, void* out, int32_t B,
+                                        int32_t H, int32_t head_dim, int32_t slot, int64_t cache_rows, int64_t bias_stride,
+                                        int32_t table_rows, float q_scale, void* stream) {
+    HK_REQUIRE(qkv && cos_table && sin_table && pos0 && k_cache && v_cache && out, "hk_decode_attn_rope_bf16: null pointer");
+    HK_REQUIRE(B > 0 && B < 65536 && H > 0 && (head_dim == 64 || head_dim == 128),
+               "hk_decode_attn_rope_bf16: bad shape B=%d H=%d head_dim=%d", B, H, head_dim);
+    HK_REQUIRE(slot >= 0 && slot < cache_rows && slot < 12288,
+               "hk_decode_attn_rope_bf16: slot %d outside the cache (%ld rows; at most 12288 keys: the score row lives in LDS)", slot,
+               (long)cache_rows);
+    HK_REQUIRE(pos_add >= 0 && pos_add < table_rows, "hk_decode_attn_rope_bf16: position offset %d outside the rotary table (%d rows)",
+               pos_add, table_rows);
+    HK_REQUIRE(key_bias == nullptr || bias_stride > slot, "hk_decode_attn_rope_bf16: bias_stride <= slot");
+    HK_REQUIRE(((uintptr_t)qkv | (uintptr_t)k_cache | (uintptr_t)v_cache | (uintptr_t)out) % 16 == 0,
+               "hk_decode_attn_rope_bf16: operands must be 16-byte aligned");
+    DecodeAttnParams p = {};
+    p.q = reinterpret_cast<const __bf16*>(qkv);
+    p.kc = reinterpret_cast<__bf16*>(k_cache);
+    p.vc = reinterpret_cast<__bf16*>(v_cache);
+    p.key_bias = key_bias;
+    p.out = reinterpret_cast<__bf16*>(out);
+    p.cos_t = cos_table;
+    p.sin_t = sin_table;
+    p.pos0 = pos0;
+    p.pos_add = pos_add;
+    p.slot = slot;
+    p.qscale = q_scale;
+    p.H = H;
+    p.n_keys = slot + 1;
+    p.cache_rows = cache_rows;
+    p.bias_stride = bias_stride;
+    const int rc = dispatch_decode_attn<true>(p, B, head_dim, reinterpret_cast<hipStream_t>(stream));
+    if (rc != HK_OK) return rc;
+    HK_CHECK_LAUNCH("hk_decode_attn_rope_bf16");
     return HK_OK;
 }
 
 extern "C" int hk_argmax_f32(const float* logits, int64_t* out, int32_t rows, int32_t V, int64_t ld, void* stream) {
     HK_REQUIRE(logits && out && rows > 0 && V > 0 && ld >= V, "hk_argmax_f32: bad arguments rows=%d V=%d", rows, V);
-    hipLaunchKernelGGL(hk_argmax_kernel, dim3((unsigned)rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), logits, out, V, ld);
+    hipLaunchKernelGGL(hk_argmax_kernel, dim3((unsigned)rows), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), logits, out, V, ld);
     HK_CHECK_LAUNCH("hk_argmax_f32");
     return HK_OK;
 }

@@ -13,6 +13,7 @@ cache row.  With 1-16 rows each projection streams its weights once (13.2 GB per
 There is no CPU path: everything enqueues C-ABI calls of libhawkeye_hip.so.
 """
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -26,7 +27,7 @@ MAX_ROWS = 16          # sequences per step hk_gemv_bf16 takes
 ROW_GRANULE = 64       # cache rows are allocated in multiples of this, so nearby prompt lengths share one plan
 
 # how a step's run-time integers enter the argument tuple of a planned call
-_STATIC, _ROPE, _ATTN = 0, 1, 2
+_STATIC, _ROPE, _ATTN, _FUSED = 0, 1, 2, 3
 
 
 class _DecodePlan:
@@ -50,6 +51,8 @@ class LlamaGenerator:
             raise RuntimeError("LlamaGenerator needs the interleaved gate|up weight layout (HK_LLM_SWIGLU=0 is a prefill A/B aid)")
         self.pre, self.cfg, self.device, self.lib = prefill, prefill.cfg, prefill.device, prefill.lib
         self.pool = _Pool(self.device)
+        # HK_DECODE_FUSED_ATTN=0: rotary / cache append and the attention as two launches (A/B aid; same results)
+        self.fused_attn = os.environ.get("HK_DECODE_FUSED_ATTN", "1") != "0"
         self.plans: Dict[Tuple[int, int, bool], _DecodePlan] = {}
         self.k_cache: Optional[torch.Tensor] = None     # [layers, B, rows, D] views of the last call (inspection / tests)
         self.v_cache: Optional[torch.Tensor] = None
@@ -111,12 +114,18 @@ class LlamaGenerator:
             kc, vc = P(ws["kc"][i]), P(ws["vc"][i])
             norm(w[o + "n1"])
             gemv(xn, w[o + "qkv"], qkv, 3 * D, D)
-            # args 4 (pos_add) and 11 (slot) are set per step
-            steps.append((lib.hk_decode_rope_append, [qkv, P(w["cos"]), P(w["sin"]), P(ws["pos0"]), 0, q, kc, vc, B, H, hd, 0, rows,
-                                                      cfg.max_position_embeddings, qscale], _ROPE, "hk_decode_rope_append"))
-            # arg 8 (n_keys) is set per step
-            steps.append((lib.hk_decode_attn_bf16, [q, kc, vc, P(ws["kbias"]) if masked else None, att, B, H, hd, 0, rows, rows],
-                          _ATTN, "hk_decode_attn_bf16"))
+            if self.fused_attn:
+                # rotary + cache append + attention in one launch; args 4 (pos_add) and 12 (slot) are set per step
+                steps.append((lib.hk_decode_attn_rope_bf16, [qkv, P(w["cos"]), P(w["sin"]), P(ws["pos0"]), 0, kc, vc,
+                                                             P(ws["kbias"]) if masked else None, att, B, H, hd, 0, rows, rows,
+                                                             cfg.max_position_embeddings, qscale], _FUSED, "hk_decode_attn_rope_bf16"))
+            else:
+                # args 4 (pos_add) and 11 (slot) are set per step
+                steps.append((lib.hk_decode_rope_append, [qkv, P(w["cos"]), P(w["sin"]), P(ws["pos0"]), 0, q, kc, vc, B, H, hd, 0, rows,
+                                                          cfg.max_position_embeddings, qscale], _ROPE, "hk_decode_rope_append"))
+                # arg 8 (n_keys) is set per step
+                steps.append((lib.hk_decode_attn_bf16, [q, kc, vc, P(ws["kbias"]) if masked else None, att, B, H, hd, 0, rows, rows],
+                              _ATTN, "hk_decode_attn_bf16"))
             gemv(att, w[o + "o"], x, D, D, residual=x, out_f32=True)
             norm(w[o + "n2"])
             gemv(xn, w[o + "gu"], act, 2 * I, D, act="swiglu")
@@ -133,6 +142,8 @@ class LlamaGenerator:
                 args[4], args[11] = t, S + t
             elif kind == _ATTN:
                 args[8] = S + t + 1
+            elif kind == _FUSED:
+                args[4], args[12] = t, S + t
             rc = fn(*args, stream)
             if rc != 0:
                 L.check(rc, name)

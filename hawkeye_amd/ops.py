@@ -420,6 +420,30 @@ def decode_attn(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, n
     return out
 
 
+def decode_attn_rope(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, pos0: torch.Tensor, pos_add: int,
+                     k_cache: torch.Tensor, v_cache: torch.Tensor, slot: int, H: int, head_dim: int, q_scale: float,
+                     key_bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """decode_rope_append + decode_attn over cache rows [0, slot] in one launch: bf16 [B, H*hd]."""
+    _need(qkv, torch.bfloat16, "qkv")
+    _need(pos0, torch.int32, "pos0")
+    _need(k_cache, torch.bfloat16, "k_cache")
+    _need(v_cache, torch.bfloat16, "v_cache")
+    B, D = qkv.shape[0], H * head_dim
+    if tuple(qkv.shape) != (B, 3 * D) or not qkv.is_contiguous() or k_cache.shape != v_cache.shape or k_cache.dim() != 3 \
+            or k_cache.shape[0] != B or k_cache.shape[2] != D or not k_cache.is_contiguous() or not v_cache.is_contiguous():
+        raise RuntimeError("decode_attn_rope: qkv [B, 3*H*hd], caches contiguous [B, rows, H*hd]")
+    if pos0.numel() != B or int(pos0.min()) < 0 or int(pos0.max()) + pos_add >= cos.shape[0]:
+        raise RuntimeError("decode_attn_rope: positions outside the rotary table")
+    if key_bias is not None:
+        _need(key_bias, torch.float32, "key_bias")
+    out = torch.empty((B, D), dtype=torch.bfloat16, device=qkv.device)
+    L.check(L.load().hk_decode_attn_rope_bf16(qkv.data_ptr(), cos.data_ptr(), sin.data_ptr(), pos0.data_ptr(), pos_add,
+                                              k_cache.data_ptr(), v_cache.data_ptr(), _ptr(key_bias), out.data_ptr(), B, H, head_dim,
+                                              slot, k_cache.shape[1], 0 if key_bias is None else key_bias.stride(0), cos.shape[0],
+                                              q_scale, _stream()), "hk_decode_attn_rope_bf16")
+    return out
+
+
 def argmax(logits: torch.Tensor) -> torch.Tensor:
     """fp32 [rows, V] -> int64 [rows], the lowest index of the largest value."""
     _need(logits, torch.float32, "logits")

@@ -242,6 +242,14 @@ int hk_decode_attn_bf16(const void* q, const void* k_cache, const void* v_cache,
                         int32_t B, int32_t H, int32_t head_dim, int32_t n_keys, int64_t cache_rows, int64_t bias_stride,
                         void* stream);
 
+/* hk_decode_rope_append + hk_decode_attn_bf16 in one launch (the workgroup of a (sequence, head) is the only reader of that
+ * head's new cache row, so it writes the row itself): qkv as hk_decode_rope_append takes it, n_keys = slot + 1.  Same
+ * results as the two calls. */
+int hk_decode_attn_rope_bf16(const void* qkv, const float* cos_table, const float* sin_table, const int32_t* pos0,
+                             int32_t pos_add, void* k_cache, void* v_cache, const float* key_bias, void* out, int32_t B,
+                             int32_t H, int32_t head_dim, int32_t slot, int64_t cache_rows, int64_t bias_stride,
+                             int32_t table_rows, float q_scale, void* stream);
+
 /* Greedy next token (do_sample=False, num_beams=1): out[r] = index of the largest of logits[r, 0:V] (row stride ld),
  * the lowest index among equals. */
 int hk_argmax_f32(const float* logits, int64_t* out, int32_t rows, int32_t V, int64_t ld, void* stream);

@@ -140,6 +140,30 @@ def test_decode_attention_matches_fp32_softmax(B, H, hd, n, rows, masked):
     assert _rel(got, ref) < 6e-3
 
 
+@pytest.mark.parametrize("B,H,hd,slot,rows,masked", [(1, 32, 128, 352, 448, False), (3, 2, 128, 96, 128, True), (2, 12, 64, 0, 8, False),
+                                                     (2, 4, 64, 700, 704, True)])
+def test_fused_rope_append_attention_equals_the_two_launches(B, H, hd, slot, rows, masked):
+    D, P = H * hd, 1024
+    qkv = _rand((B, 3 * D), 12, 1.0, torch.bfloat16)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))
+    fr = torch.einsum("i,j->ij", torch.arange(P).float(), inv)
+    cos, sin = fr.cos().to(DEV).contiguous(), fr.sin().to(DEV).contiguous()
+    pos0 = torch.tensor([slot, max(slot - 9, 0), max(slot - 40, 0)][:B], dtype=torch.int32, device=DEV)
+    kc, vc = _rand((B, rows, D), 13, 1.0, torch.bfloat16), _rand((B, rows, D), 14, 1.0, torch.bfloat16)
+    kc2, vc2 = kc.clone(), vc.clone()
+    bias = None
+    if masked:
+        bias = torch.zeros((B, rows), dtype=torch.float32, device=DEV)
+        for b in range(B):
+            bias[b, : int(slot - pos0[b])] = -10000.0
+    qs = hd ** -0.5 * LOG2E
+    q = ops.decode_rope_append(qkv, cos, sin, pos0, 2, kc, vc, slot, H, hd, qs)
+    two = ops.decode_attn(q, kc, vc, slot + 1, H, hd, bias)
+    one = ops.decode_attn_rope(qkv, cos, sin, pos0, 2, kc2, vc2, slot, H, hd, qs, bias)
+    assert torch.equal(kc, kc2) and torch.equal(vc, vc2)
+    assert _rel(one, two) < 1e-5 if not torch.equal(one, two) else True
+
+
 def test_argmax_lowest_index_among_equals():
     x = _rand((5, 32000), 11)
     x[1, 777] = 50.0
