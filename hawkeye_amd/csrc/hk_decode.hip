@@ -11,13 +11,15 @@
 namespace {
 
 struct GemvParams {
-    const __bf16* x;
+    const void* x;          // bf16 [M][K], or fp32 when norm_w is set
     const __bf16* W;
     void* out;
     const float* res;
+    const float* norm_w;    // RMSNorm weight [K] or null
     int M, N, K;
     int64_t ldx, ldo;
     int out_f32, act;
+    float eps;
 };
 
 __device__ __forceinline__ float silu_mul_d(const float g, const float u) {   // the GEMM epilogue's form (hk_gemm.hip)
@@ -31,8 +33,13 @@ __device__ __forceinline__ float silu_mul_d(const float g, const float u) {   //
 // (EXEC-masked to i < M, zero otherwise); the two 8-element halves are the A / B operands of two MFMAs (any k order works
 // for a dot product as long as both operands use the same one).  The accumulator of lane (j = lane & 15, q) is
 // y[m = j][n0 + 4 q .. 4 q + 3].  The K slices meet in LDS and are summed in wave order (deterministic).
-template <int KS>
+// W loads run one group of U K-blocks ahead of the MFMAs (two groups = 16 x 16 B per lane in flight).
+// NORM: x is the fp32 residual stream and the operand is RMSNorm(x) * norm_w (modeling_llama.py:57-75) rounded to bf16 --
+// hk_rmsnorm's arithmetic, without its launch and its [M, K] round trip: every workgroup sums the squares of the M <= 4
+// rows itself (16 KB each from L2, while its first weight loads are in flight) and normalises the fragments as it loads them.
+template <int KS, int MODE>   // MODE 0: x fragments from global memory; 1: bf16 x staged in LDS; 2: RMSNorm(x) staged in LDS
 __global__ __launch_bounds__(KS * 64) void hk_gemv_kernel(const GemvParams p) {
+    constexpr bool NORM = MODE == 2, XLDS = MODE != 0;
     __shared__ f32x4 red[KS][64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -42,48 +49,147 @@ __global__ __launch_bounds__(KS * 64) void hk_gemv_kernel(const GemvParams p) {
     const int per = (nblk + KS - 1) / KS;
     const int b0 = wave * per, b1 = min(nblk, b0 + per);
     const bool mvalid = i < p.M;
-    const __bf16* wp = p.W + (int64_t)min(n0 + i, p.N - 1) * p.K + q * 16 + (int64_t)b0 * 64;   // rows past N: a copy of the last, never stored
-    const __bf16* xp = p.x + (int64_t)(mvalid ? i : 0) * p.ldx + q * 16 + (int64_t)b0 * 64;
+    const int64_t koff = q * 16 + (int64_t)b0 * 64;
+    const __bf16* wp = p.W + (int64_t)min(n0 + i, p.N - 1) * p.K + koff;   // rows past N: a copy of the last, never stored
+    const __bf16* xb = reinterpret_cast<const __bf16*>(p.x) + (int64_t)(mvalid ? i : 0) * p.ldx + koff;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-    constexpr int U = 4;   // K-blocks whose loads are issued together: 8 x 16 B of W per lane in flight
-    int b = b0;
-    for (; b + U <= b1; b += U) {
-        bf16x8 w[U][2], xv[U][2];
+    constexpr int U = 4;   // K-blocks per group
+    bf16x8 wc[U][2];
+    auto load_w = [&](bf16x8 (&w)[U][2], const __bf16* src) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            w[u][0] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + u * 64));
-            w[u][1] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + u * 64 + 8));
+            w[u][0] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(src + u * 64));
+            w[u][1] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(src + u * 64 + 8));
         }
+    };
+    int b = b0;
+    extern __shared__ __attribute__((aligned(16))) char xs_raw[];   // NORM: the normalised rows in bf16, [M][K + 64]
+    const int xld = p.K + 64;                                       // row stride (elements): rows 128 B apart in the banks
+    if constexpr (NORM) {
+        // Row statistics, then bf16(norm_w * (x * rinv)) of all M rows into LDS: the main loop reads its B operands from
+        // there, so its only global loads are the weights.  The statistics' loads are older than the weight loads below and
+        // return first; the second pass over x hits L2.
+        __shared__ float ssq[KS][4];
+        constexpr int NV = 16 / KS > 0 ? 16 / KS : 1;   // K <= NV * KS * 256 = 4096 elements, checked by the host
+        float ss[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            xv[u][0] = zero;
-            xv[u][1] = zero;
-            if (mvalid) {
-                xv[u][0] = *reinterpret_cast<const bf16x8*>(xp + u * 64);
-                xv[u][1] = *reinterpret_cast<const bf16x8*>(xp + u * 64 + 8);
+        for (int m = 0; m < 4; ++m)
+            if (m < p.M) {
+                f32x4 v[NV];
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    const int k = (j * KS * 64 + tid) * 4;
+                    v[j] = k < p.K ? *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.x) + (int64_t)m * p.ldx + k)
+                                   : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int j = 0; j < NV; ++j) ss[m] += v[j][0] * v[j][0] + v[j][1] * v[j][1] + v[j][2] * v[j][2] + v[j][3] * v[j][3];
+            }
+        if (b + U <= b1) load_w(wc, wp);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) ss[m] += __shfl_xor(ss[m], o, 64);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) ssq[wave][m] = ss[m];
+        }
+        __syncthreads();
+        __bf16* xs = reinterpret_cast<__bf16*>(xs_raw);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            if (m < p.M) {
+                float tot = 0.f;
+#pragma unroll
+                for (int w = 0; w < KS; ++w) tot += ssq[w][m];
+                const float rinv = rsqrtf(tot / (float)p.K + p.eps);
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    const int k = (j * KS * 64 + tid) * 4;
+                    if (k < p.K) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.x) + (int64_t)m * p.ldx + k);
+                        const f32x4 g = *reinterpret_cast<const f32x4*>(p.norm_w + k);
+                        u32x2 o;
+                        o[0] = pack_bf16x2(g[0] * (v[0] * rinv), g[1] * (v[1] * rinv));
+                        o[1] = pack_bf16x2(g[2] * (v[2] * rinv), g[3] * (v[3] * rinv));
+                        *reinterpret_cast<u32x2*>(xs + m * xld + k) = o;
+                    }
+                }
+            }
+        __syncthreads();
+    } else if constexpr (XLDS) {
+        // the operand rows -> LDS (their loads are older than the weight loads and return first): the main loop's only
+        // global loads are then the weights, and no MFMA waits on an x fragment queued behind them
+        __bf16* xs = reinterpret_cast<__bf16*>(xs_raw);
+        const int cpr = p.K >> 3, total = p.M * cpr;          // 16-byte chunks per row / in all
+        for (int c0 = tid; c0 < total; c0 += 4 * KS * 64) {
+            u32x4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = min(c0 + j * KS * 64, total - 1), m = c / cpr;
+                v[j] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const __bf16*>(p.x) + (int64_t)m * p.ldx + (c - m * cpr) * 8);
+            }
+            if (c0 == tid && b + U <= b1) load_w(wc, wp);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = c0 + j * KS * 64, m = c / cpr;
+                if (c < total) *reinterpret_cast<u32x4*>(xs + m * xld + (c - m * cpr) * 8) = v[j];
             }
         }
+        if (tid >= total && b + U <= b1) load_w(wc, wp);      // threads without a chunk still start their weight loads
+        __syncthreads();
+    } else {
+        if (b + U <= b1) load_w(wc, wp);
+    }
+    const __bf16* xl = reinterpret_cast<const __bf16*>(xs_raw) + (mvalid ? i : 0) * xld + koff;
+    // the B operand of one 64-element block: bf16 x from global memory, or the normalised row from LDS
+    auto load_x = [&](bf16x8& x0, bf16x8& x1, int u) __attribute__((always_inline)) {
+        x0 = zero;
+        x1 = zero;
+        if (mvalid) {
+            if constexpr (XLDS) {
+                x0 = *reinterpret_cast<const bf16x8*>(xl + u * 64);
+                x1 = *reinterpret_cast<const bf16x8*>(xl + u * 64 + 8);
+            } else {
+                x0 = *reinterpret_cast<const bf16x8*>(xb + u * 64);
+                x1 = *reinterpret_cast<const bf16x8*>(xb + u * 64 + 8);
+            }
+        }
+    };
+    for (; b + U <= b1; b += U) {
+        bf16x8 wn[U][2], xv[U][2];
+        const bool more = b + 2 * U <= b1;      // wave-uniform
+        if (more) load_w(wn, wp + U * 64);
+#pragma unroll
+        for (int u = 0; u < U; ++u) load_x(xv[u][0], xv[u][1], u);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[u][0], xv[u][0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[u][1], xv[u][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[u][0], xv[u][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[u][1], xv[u][1], acc, 0, 0, 0);
+        }
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                wc[u][0] = wn[u][0];
+                wc[u][1] = wn[u][1];
+            }
         }
         wp += U * 64;
-        xp += U * 64;
+        xb += U * 64;
+        xl += U * 64;
     }
     for (; b < b1; ++b) {
         const bf16x8 w0 = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp));
         const bf16x8 w1 = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + 8));
-        bf16x8 x0 = zero, x1 = zero;
-        if (mvalid) {
-            x0 = *reinterpret_cast<const bf16x8*>(xp);
-            x1 = *reinterpret_cast<const bf16x8*>(xp + 8);
-        }
+        bf16x8 x0, x1;
+        load_x(x0, x1, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x0, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, x1, acc, 0, 0, 0);
         wp += 64;
-        xp += 64;
+        xb += 64;
+        xl += 64;
     }
     if (KS > 1) {
         red[wave][lane] = acc;
@@ -371,21 +477,24 @@ extern "C" int hk_gemv_bf16(const hk_gemv_desc* d, void* stream) {
     HK_REQUIRE(d && d->x && d->W && d->out, "hk_gemv_bf16: null pointer");
     HK_REQUIRE(d->M >= 1 && d->M <= 16, "hk_gemv_bf16: M=%d rows (1..16: the decode step; larger batches go through hk_gemm_bf16)", d->M);
     HK_REQUIRE(d->N > 0 && d->K > 0 && d->K % 64 == 0, "hk_gemv_bf16: N=%d must be positive, K=%d a multiple of 64", d->N, d->K);
-    HK_REQUIRE(d->act != HK_ACT_SWIGLU || d->N % 4 == 0, "hk_gemv_bf16: swiglu needs N=%d to be a multiple of 4", d->N);
     HK_REQUIRE(d->act == HK_ACT_NONE || d->act == HK_ACT_SWIGLU, "hk_gemv_bf16: act %d not supported (none, swiglu)", d->act);
+    HK_REQUIRE(d->act != HK_ACT_SWIGLU || d->N % 4 == 0, "hk_gemv_bf16: swiglu needs N=%d to be a multiple of 4", d->N);
     HK_REQUIRE(d->act != HK_ACT_SWIGLU || (d->out_f32 == 0 && d->residual == nullptr && d->ldo >= d->N / 2 && d->ldo % 2 == 0),
                "hk_gemv_bf16: swiglu writes bf16 [M][N/2], no residual");
     HK_REQUIRE(d->act == HK_ACT_SWIGLU || (d->ldo >= d->N && d->ldo % 4 == 0), "hk_gemv_bf16: ldo=%ld must be >= N and a multiple of 4",
                (long)d->ldo);
     HK_REQUIRE(d->ldx >= d->K && d->ldx % 8 == 0, "hk_gemv_bf16: ldx=%ld must be >= K and a multiple of 8", (long)d->ldx);
     HK_REQUIRE(d->residual == nullptr || d->out_f32 != 0, "hk_gemv_bf16: a residual needs the fp32 output");
-    HK_REQUIRE(((uintptr_t)d->x | (uintptr_t)d->W | (uintptr_t)d->out | (uintptr_t)d->residual) % 16 == 0,
+    HK_REQUIRE(((uintptr_t)d->x | (uintptr_t)d->W | (uintptr_t)d->out | (uintptr_t)d->residual | (uintptr_t)d->norm_weight) % 16 == 0,
                "hk_gemv_bf16: operands must be 16-byte aligned");
+    HK_REQUIRE(d->norm_weight == nullptr || (d->M <= 4 && d->norm_eps > 0.f && d->x != d->out && d->K <= 4096),
+               "hk_gemv_bf16: the fused RMSNorm takes M <= 4 fp32 rows of K <= 4096, eps > 0, and cannot run in place");
     GemvParams p;
-    p.x = reinterpret_cast<const __bf16*>(d->x);
+    p.x = d->x;
     p.W = reinterpret_cast<const __bf16*>(d->W);
     p.out = d->out;
     p.res = d->residual;
+    p.norm_w = d->norm_weight;
     p.M = d->M;
     p.N = d->N;
     p.K = d->K;
@@ -393,6 +502,7 @@ extern "C" int hk_gemv_bf16(const hk_gemv_desc* d, void* stream) {
     p.ldo = d->ldo;
     p.out_f32 = d->out_f32;
     p.act = d->act;
+    p.eps = d->norm_eps;
     // K slices (waves per workgroup): enough waves for ~8 per CU, at least 4 K-blocks per slice
     const int nb = (d->N + 15) / 16, nblk = d->K / 64;
     int ks = 1;
@@ -401,13 +511,25 @@ extern "C" int hk_gemv_bf16(const hk_gemv_desc* d, void* stream) {
     if (force == 1 || force == 2 || force == 4 || force == 8 || force == 16) ks = force;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)nb);
+    // operand rows staged in LDS when they fit beside a few workgroups per CU (always for the fused norm: K <= 4096, M <= 4)
+    const size_t xbytes = (size_t)p.M * (p.K + 64) * 2;
+    static const int xl_env = getenv("HK_GEMV_XLDS") ? atoi(getenv("HK_GEMV_XLDS")) : 1;   // A/B aid: 0 = fragments from global memory
+    const int mode = p.norm_w ? 2 : (xl_env != 0 && xbytes <= 40 * 1024) ? 1 : 0;      // + up to 16 KB of static LDS stays under 64 KB
+    const size_t xlds = mode ? xbytes : 0;
+#define HK_GEMV(KS_)                                                                                        \
+    case KS_:                                                                                               \
+        if (mode == 2) hipLaunchKernelGGL((hk_gemv_kernel<KS_, 2>), grid, dim3(KS_ * 64), xlds, s, p);      \
+        else if (mode == 1) hipLaunchKernelGGL((hk_gemv_kernel<KS_, 1>), grid, dim3(KS_ * 64), xlds, s, p); \
+        else hipLaunchKernelGGL((hk_gemv_kernel<KS_, 0>), grid, dim3(KS_ * 64), 0, s, p);                   \
+        break;
     switch (ks) {
-        case 1: hipLaunchKernelGGL((hk_gemv_kernel<1>), grid, dim3(64), 0, s, p); break;
-        case 2: hipLaunchKernelGGL((hk_gemv_kernel<2>), grid, dim3(128), 0, s, p); break;
-        case 4: hipLaunchKernelGGL((hk_gemv_kernel<4>), grid, dim3(256), 0, s, p); break;
-        case 8: hipLaunchKernelGGL((hk_gemv_kernel<8>), grid, dim3(512), 0, s, p); break;
-        default: hipLaunchKernelGGL((hk_gemv_kernel<16>), grid, dim3(1024), 0, s, p); break;
+        HK_GEMV(1) HK_GEMV(2) HK_GEMV(4) HK_GEMV(8)
+        default:
+            if (mode == 2) hipLaunchKernelGGL((hk_gemv_kernel<16, 2>), grid, dim3(1024), xlds, s, p);
+            else if (mode == 1) hipLaunchKernelGGL((hk_gemv_kernel<16, 1>), grid, dim3(1024), xlds, s, p);
+            else hipLaunchKernelGGL((hk_gemv_kernel<16, 0>), grid, dim3(1024), 0, s, p);
     }
+#undef HK_GEMV
     HK_CHECK_LAUNCH("hk_gemv_bf16");
     return HK_OK;
 }

@@ -53,6 +53,8 @@ class LlamaGenerator:
         self.pool = _Pool(self.device)
         # HK_DECODE_FUSED_ATTN=0: rotary / cache append and the attention as two launches (A/B aid; same results)
         self.fused_attn = os.environ.get("HK_DECODE_FUSED_ATTN", "1") != "0"
+        # HK_DECODE_FUSED_NORM=0: every RMSNorm as its own launch (A/B aid)
+        self.fused_norm = os.environ.get("HK_DECODE_FUSED_NORM", "1") != "0"
         self.plans: Dict[Tuple[int, int, bool], _DecodePlan] = {}
         self.k_cache: Optional[torch.Tensor] = None     # [layers, B, rows, D] views of the last call (inspection / tests)
         self.v_cache: Optional[torch.Tensor] = None
@@ -104,16 +106,23 @@ class LlamaGenerator:
             plan.keep.append(d)
             steps.append((lib.hk_gemv_bf16, [C.byref(d)], _STATIC, "hk_gemv_bf16"))
 
-        def norm(gamma):
-            steps.append((lib.hk_rmsnorm, [x, L.HK_DT_F32, P(gamma), xn, B, D, cfg.rms_norm_eps], _STATIC, "hk_rmsnorm"))
+        # RMSNorm fused into the projection that consumes it (hk_gemv_desc.norm_weight, up to 4 sequences): the stream's fp32 rows
+        # are the operand; otherwise a hk_rmsnorm launch writes xn first
+        fuse_norm = self.fused_norm and B <= 4
+
+        def normed_gemv(gamma, W, out, N, **kw):
+            if fuse_norm:
+                gemv(x, W, out, N, D, norm_weight=P(gamma), norm_eps=cfg.rms_norm_eps, **kw)
+            else:
+                steps.append((lib.hk_rmsnorm, [x, L.HK_DT_F32, P(gamma), xn, B, D, cfg.rms_norm_eps], _STATIC, "hk_rmsnorm"))
+                gemv(xn, W, out, N, D, **kw)
 
         # the token chosen by the previous step (or by the prefill) -> its embedding = the new residual stream
         steps.append((lib.hk_embed_splice, [P(ws["tok"]), P(w["embed"]), None, L.HK_DT_BF16, x, B, D], _STATIC, "hk_embed_splice"))
         for i in range(Lyr):
             o = f"l{i}."
             kc, vc = P(ws["kc"][i]), P(ws["vc"][i])
-            norm(w[o + "n1"])
-            gemv(xn, w[o + "qkv"], qkv, 3 * D, D)
+            normed_gemv(w[o + "n1"], w[o + "qkv"], qkv, 3 * D)
             if self.fused_attn:
                 # rotary + cache append + attention in one launch; args 4 (pos_add) and 12 (slot) are set per step
                 steps.append((lib.hk_decode_attn_rope_bf16, [qkv, P(w["cos"]), P(w["sin"]), P(ws["pos0"]), 0, kc, vc,
@@ -127,11 +136,9 @@ class LlamaGenerator:
                 steps.append((lib.hk_decode_attn_bf16, [q, kc, vc, P(ws["kbias"]) if masked else None, att, B, H, hd, 0, rows, rows],
                               _ATTN, "hk_decode_attn_bf16"))
             gemv(att, w[o + "o"], x, D, D, residual=x, out_f32=True)
-            norm(w[o + "n2"])
-            gemv(xn, w[o + "gu"], act, 2 * I, D, act="swiglu")
+            normed_gemv(w[o + "n2"], w[o + "gu"], act, 2 * I, act="swiglu")
             gemv(act, w[o + "down"], x, D, I, residual=x, out_f32=True)
-        norm(w["norm"])
-        gemv(xn, w["lm_head"], P(ws["logits"]), V, D, out_f32=True, ldo=ws["logits"].stride(0))
+        normed_gemv(w["norm"], w["lm_head"], P(ws["logits"]), V, out_f32=True, ldo=ws["logits"].stride(0))
         steps.append((lib.hk_argmax_f32, [P(ws["logits"]), P(ws["tok"]), B, V, ws["logits"].stride(0)], _STATIC, "hk_argmax_f32"))
         return plan
 

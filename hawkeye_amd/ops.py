@@ -349,7 +349,8 @@ def rope_(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, H: int, head_
     return qkv
 
 
-def gemv_desc(x, W, out, M, N, K, *, ldx=None, ldo=None, residual=None, out_f32=False, act="none") -> L.HkGemvDesc:
+def gemv_desc(x, W, out, M, N, K, *, ldx=None, ldo=None, residual=None, out_f32=False, act="none", norm_weight=None,
+              norm_eps=0.0) -> L.HkGemvDesc:
     """Descriptor of one hk_gemv_bf16 call on raw pointers (the decode plan builds these once)."""
     d = L.HkGemvDesc()
     d.x, d.W, d.out, d.residual = x, W, out, residual
@@ -357,15 +358,18 @@ def gemv_desc(x, W, out, M, N, K, *, ldx=None, ldo=None, residual=None, out_f32=
     d.act = {"none": L.HK_ACT_NONE, "swiglu": L.HK_ACT_SWIGLU}[act]
     d.ldx = K if ldx is None else ldx
     d.ldo = (N // 2 if act == "swiglu" else N) if ldo is None else ldo
-    d.reserved = 0
+    d.norm_weight, d.norm_eps = norm_weight, norm_eps
     return d
 
 
 def gemv(x: torch.Tensor, w: torch.Tensor, *, residual: Optional[torch.Tensor] = None, out_f32: bool = False,
-         act: str = "none") -> torch.Tensor:
+         act: str = "none", norm_weight: Optional[torch.Tensor] = None, norm_eps: float = 1e-6) -> torch.Tensor:
     """x bf16 [M <= 16, K] . w bf16 [N, K]^T -> [M, N] (bf16, or fp32 with out_f32; + fp32 residual), or
-    [M, N/2] = silu(gate) * up for act="swiglu" on interleaved (gate, up) weight rows.  The decode step's Linear."""
-    _need(x, torch.bfloat16, "x")
+    [M, N/2] = silu(gate) * up for act="swiglu" on interleaved (gate, up) weight rows.  The decode step's Linear.
+    norm_weight fp32 [K]: x is fp32 [M <= 4, K] and the operand is RMSNorm(x) * norm_weight (fused hk_rmsnorm)."""
+    if norm_weight is not None:
+        _need(norm_weight, torch.float32, "norm_weight")
+    _need(x, torch.float32 if norm_weight is not None else torch.bfloat16, "x")
     _need(w, torch.bfloat16, "w")
     if x.dim() != 2 or w.dim() != 2 or x.shape[1] != w.shape[1] or not x.is_contiguous() or not w.is_contiguous():
         raise RuntimeError("gemv: x [M, K] and w [N, K] must be contiguous with equal K")
@@ -376,7 +380,8 @@ def gemv(x: torch.Tensor, w: torch.Tensor, *, residual: Optional[torch.Tensor] =
         if tuple(residual.shape) != (M, N) or not residual.is_contiguous():
             raise RuntimeError("gemv: residual must be contiguous fp32 [M, N]")
     out = torch.empty((M, N // 2 if act == "swiglu" else N), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
-    d = gemv_desc(x.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, K, residual=_ptr(residual), out_f32=out_f32, act=act)
+    d = gemv_desc(x.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, K, residual=_ptr(residual), out_f32=out_f32, act=act,
+                  norm_weight=_ptr(norm_weight), norm_eps=norm_eps if norm_weight is not None else 0.0)
     L.check(L.load().hk_gemv_bf16(C.byref(d), _stream()), "hk_gemv_bf16")
     return out
 

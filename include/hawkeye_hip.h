@@ -210,7 +210,7 @@ int hk_rope_bf16(void* qkv, const float* cos_table, const float* sin_table, cons
  * 482-611, 744-773).  With 1-16 rows every projection streams its weights once: these entries are HBM-bound. */
 
 /* y[M, N] = x[M, K] . W[N, K]^T for M <= 16 rows (nn.Linear without bias: q/k/v, o_proj, gate/up, down_proj, lm_head;
- * modeling_llama.py:134-140, 160-163, 622).  x bf16 (row stride ldx), W bf16 row-major; out bf16 or fp32 (row stride ldo);
+ * modeling_llama.py:134-140, 160-163, 622).  x bf16 (row stride ldx; fp32 with norm_weight), W bf16 row-major; out bf16 or fp32 (row stride ldo);
  * residual fp32 with out's layout or NULL, added before the store (may alias out: the residual stream, :297-307);
  * act HK_ACT_SWIGLU: W rows interleaved (gate_0, up_0, ...) and out[M, N/2] = silu(gate) * up in bf16, as hk_gemm_bf16. */
 typedef struct hk_gemv_desc {
@@ -222,7 +222,10 @@ typedef struct hk_gemv_desc {
     int32_t out_f32;
     int64_t ldx, ldo;
     int32_t act;
-    int32_t reserved;      /* 0 */
+    float norm_eps;
+    /* fused LlamaRMSNorm (modeling_llama.py:57-75) of the input, M <= 4: x is then the fp32 residual stream [M, K] and the
+     * operand is bf16(norm_weight * (x * rsqrt(mean(x^2) + norm_eps))), what hk_rmsnorm would have written; NULL = x is bf16 */
+    const float* norm_weight;
 } hk_gemv_desc;
 int hk_gemv_bf16(const hk_gemv_desc* d, void* stream);
 

@@ -73,6 +73,25 @@ def test_gemv_swiglu_matches_the_gemm_epilogue_and_fp32(M, I, K):
     assert _rel(got, big.float()) < 6e-3
 
 
+@pytest.mark.parametrize("M,N,K,act", [(1, 12288, 4096, "none"), (4, 22016, 4096, "swiglu"), (2, 320, 256, "none"), (3, 32000, 4096, "none")])
+def test_gemv_with_fused_rmsnorm_matches_the_two_launches(M, N, K, act):
+    x = _rand((M, K), 15, 2.0)
+    gamma = (1.0 + 0.1 * _rand((K,), 16)).contiguous()
+    w = _rand((N, K), 17, 0.03, torch.bfloat16)
+    xn = ops.rmsnorm(x, gamma, 1e-6)
+    two = ops.gemv(xn, w, act=act, out_f32=(act == "none"))
+    one = ops.gemv(x, w, act=act, out_f32=(act == "none"), norm_weight=gamma, norm_eps=1e-6)
+    # the row statistic is summed in another order: one ulp of rinv can move a bf16 rounding of single operand elements
+    assert _rel(one, two) < 2e-3
+    xr = x * torch.rsqrt((x * x).mean(-1, keepdim=True) + 1e-6) * gamma
+    ref = xr @ w.float().t()
+    if act == "swiglu":
+        ref = torch.nn.functional.silu(ref[:, 0::2]) * ref[:, 1::2]
+    assert _rel(one, ref) < 8e-3
+    with pytest.raises(RuntimeError, match="M <= 4"):
+        ops.gemv(_rand((5, K), 1), w, norm_weight=gamma)
+
+
 def test_gemv_rejects_what_it_cannot_run():
     x, w = _rand((17, 256), 1, 1.0, torch.bfloat16), _rand((64, 256), 2, 1.0, torch.bfloat16)
     with pytest.raises(RuntimeError, match="1..16"):
