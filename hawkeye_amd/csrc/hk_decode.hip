@@ -503,10 +503,12 @@ extern "C" int hk_gemv_bf16(const hk_gemv_desc* d, void* stream) {
     p.out_f32 = d->out_f32;
     p.act = d->act;
     p.eps = d->norm_eps;
-    // K slices (waves per workgroup): enough waves for ~8 per CU, at least 4 K-blocks per slice
+    // K slices (waves per workgroup): about 12 waves per CU, at least 4 K-blocks per slice, at most 8 slices (measured with cold
+    // weights, tools/gemv_bench.py, us at 1 / 2 / 4 / 8 / 16 slices: qkv 24.4 23.6 21.1 22.2 26.1, o_proj 15.8 11.0 9.3 9.2 9.7,
+    // gate|up 39.9 39.8 38.1 39.0 47.4, down_proj 39.0 26.1 21.2 20.6 21.1, lm_head 52.2 52.5 50.4 51.9 62.5)
     const int nb = (d->N + 15) / 16, nblk = d->K / 64;
     int ks = 1;
-    while (ks < 16 && (long)nb * ks < 2048 && nblk / (ks * 2) >= 4) ks *= 2;
+    while (ks < 8 && (long)nb * ks < 3000 && nblk / (ks * 2) >= 4) ks *= 2;
     static const int force = getenv("HK_GEMV_KS") ? atoi(getenv("HK_GEMV_KS")) : 0;   // A/B aid
     if (force == 1 || force == 2 || force == 4 || force == 8 || force == 16) ks = force;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

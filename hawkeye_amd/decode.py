@@ -108,7 +108,7 @@ class LlamaGenerator:
 
         # RMSNorm fused into the projection that consumes it (hk_gemv_desc.norm_weight, up to 4 sequences): the stream's fp32 rows
         # are the operand; otherwise a hk_rmsnorm launch writes xn first
-        fuse_norm = self.fused_norm and B <= 4
+        fuse_norm = self.fused_norm and B <= 4 and D <= 4096
 
         def normed_gemv(gamma, W, out, N, **kw):
             if fuse_norm:
