@@ -20,6 +20,7 @@ struct GemvParams {
     int64_t ldx, ldo;
     int out_f32, act;
     float eps;
+    int tiled;              // W is hk_gemv_desc.w_tiled's block layout
 };
 
 __device__ __forceinline__ float silu_mul_d(const float g, const float u) {   // the GEMM epilogue's form (hk_gemm.hip)
@@ -50,7 +51,12 @@ __global__ __launch_bounds__(KS * 64) void hk_gemv_kernel(const GemvParams p) {
     const int b0 = wave * per, b1 = min(nblk, b0 + per);
     const bool mvalid = i < p.M;
     const int64_t koff = q * 16 + (int64_t)b0 * 64;
-    const __bf16* wp = p.W + (int64_t)min(n0 + i, p.N - 1) * p.K + koff;   // rows past N: a copy of the last, never stored
+    // row-major W: lane (i, q) reads 2 x 16 B at k = 16 q of row n0 + i, 64 elements further per K-block (rows past N: a copy of
+    // the last, never stored).  Tiled W (w_tiled): the 16 x 64 block of (row block, K-block) is 2 KB contiguous, stored as the two
+    // 1 KB wave-loads themselves ([half][lane][8 elements]) -- a wave streams one contiguous region of memory.
+    const int wstep = p.tiled ? 1024 : 64, whalf = p.tiled ? 512 : 8;
+    const __bf16* wp = p.tiled ? p.W + ((int64_t)blockIdx.x * nblk + b0) * 1024 + lane * 8
+                               : p.W + (int64_t)min(n0 + i, p.N - 1) * p.K + koff;
     const __bf16* xb = reinterpret_cast<const __bf16*>(p.x) + (int64_t)(mvalid ? i : 0) * p.ldx + koff;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -59,8 +65,8 @@ __global__ __launch_bounds__(KS * 64) void hk_gemv_kernel(const GemvParams p) {
     auto load_w = [&](bf16x8 (&w)[U][2], const __bf16* src) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            w[u][0] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(src + u * 64));
-            w[u][1] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(src + u * 64 + 8));
+            w[u][0] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(src + u * wstep));
+            w[u][1] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(src + u * wstep + whalf));
         }
     };
     int b = b0;
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(KS * 64) void hk_gemv_kernel(const GemvParams p) {
     for (; b + U <= b1; b += U) {
         bf16x8 wn[U][2], xv[U][2];
         const bool more = b + 2 * U <= b1;      // wave-uniform
-        if (more) load_w(wn, wp + U * 64);
+        if (more) load_w(wn, wp + U * wstep);
 #pragma unroll
         for (int u = 0; u < U; ++u) load_x(xv[u][0], xv[u][1], u);
 #pragma unroll
@@ -176,18 +182,18 @@ __global__ __launch_bounds__(KS * 64) void hk_gemv_kernel(const GemvParams p) {
                 wc[u][1] = wn[u][1];
             }
         }
-        wp += U * 64;
+        wp += U * wstep;
         xb += U * 64;
         xl += U * 64;
     }
     for (; b < b1; ++b) {
         const bf16x8 w0 = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp));
-        const bf16x8 w1 = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + 8));
+        const bf16x8 w1 = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + whalf));
         bf16x8 x0, x1;
         load_x(x0, x1, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x0, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, x1, acc, 0, 0, 0);
-        wp += 64;
+        wp += wstep;
         xb += 64;
         xl += 64;
     }
@@ -487,6 +493,7 @@ extern "C" int hk_gemv_bf16(const hk_gemv_desc* d, void* stream) {
     HK_REQUIRE(d->residual == nullptr || d->out_f32 != 0, "hk_gemv_bf16: a residual needs the fp32 output");
     HK_REQUIRE(((uintptr_t)d->x | (uintptr_t)d->W | (uintptr_t)d->out | (uintptr_t)d->residual | (uintptr_t)d->norm_weight) % 16 == 0,
                "hk_gemv_bf16: operands must be 16-byte aligned");
+    HK_REQUIRE(d->w_tiled == 0 || d->w_tiled == 1, "hk_gemv_bf16: w_tiled must be 0 or 1");
     HK_REQUIRE(d->norm_weight == nullptr || (d->M <= 4 && d->norm_eps > 0.f && d->x != d->out && d->K <= 4096),
                "hk_gemv_bf16: the fused RMSNorm takes M <= 4 fp32 rows of K <= 4096, eps > 0, and cannot run in place");
     GemvParams p;
@@ -503,6 +510,7 @@ extern "C" int hk_gemv_bf16(const hk_gemv_desc* d, void* stream) {
     p.out_f32 = d->out_f32;
     p.act = d->act;
     p.eps = d->norm_eps;
+    p.tiled = d->w_tiled;
     // K slices (waves per workgroup): about 12 waves per CU, at least 4 K-blocks per slice, at most 8 slices (measured with cold
     // weights, tools/gemv_bench.py, us at 1 / 2 / 4 / 8 / 16 slices: qkv 24.4 23.6 21.1 22.2 26.1, o_proj 15.8 11.0 9.3 9.2 9.7,
     // gate|up 39.9 39.8 38.1 39.0 47.4, down_proj 39.0 26.1 21.2 20.6 21.1, lm_head 52.2 52.5 50.4 51.9 62.5)

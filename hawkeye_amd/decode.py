@@ -55,6 +55,17 @@ class LlamaGenerator:
         self.fused_attn = os.environ.get("HK_DECODE_FUSED_ATTN", "1") != "0"
         # HK_DECODE_FUSED_NORM=0: every RMSNorm as its own launch (A/B aid)
         self.fused_norm = os.environ.get("HK_DECODE_FUSED_NORM", "1") != "0"
+        # Decode-only copy of the projection weights in hk_gemv_desc.w_tiled's block layout: a wave streams one contiguous
+        # region instead of 16 rows 8-22 KB apart (cold-weight sweep, row-major -> tiled: gate|up 39.5 -> 31.1 us = 5.8 TB/s,
+        # down_proj 21.0 -> 16.8, qkv 21.9 -> 18.9, lm_head 55 -> 43 = 6.1 TB/s).  Costs the weights' size again (13.5 GB for
+        # Vicuna-7B, of 288 GB); HK_DECODE_TILED=0 streams the prefill's row-major weights instead.
+        self.tiled = os.environ.get("HK_DECODE_TILED", "1") != "0"
+        self.wt: Dict[str, torch.Tensor] = {}
+        if self.tiled:
+            with torch.cuda.device(self.device):
+                for k, v in prefill.w.items():
+                    if k == "lm_head" or k.endswith((".qkv", ".o", ".gu", ".down")):
+                        self.wt[k] = ops.tile_gemv_weight(v)
         self.plans: Dict[Tuple[int, int, bool], _DecodePlan] = {}
         self.k_cache: Optional[torch.Tensor] = None     # [layers, B, rows, D] views of the last call (inspection / tests)
         self.v_cache: Optional[torch.Tensor] = None
@@ -101,8 +112,9 @@ class LlamaGenerator:
         qscale = (hd ** -0.5) * LOG2E
         steps, lib = plan.steps, self.lib
 
-        def gemv(xp, W, out, N, K, **kw):
-            d = ops.gemv_desc(xp, W.data_ptr(), out, B, N, K, **kw)
+        def gemv(xp, name, out, N, K, **kw):
+            W = self.wt[name] if self.tiled else w[name]
+            d = ops.gemv_desc(xp, W.data_ptr(), out, B, N, K, w_tiled=self.tiled, **kw)
             plan.keep.append(d)
             steps.append((lib.hk_gemv_bf16, [C.byref(d)], _STATIC, "hk_gemv_bf16"))
 
@@ -122,7 +134,7 @@ class LlamaGenerator:
         for i in range(Lyr):
             o = f"l{i}."
             kc, vc = P(ws["kc"][i]), P(ws["vc"][i])
-            normed_gemv(w[o + "n1"], w[o + "qkv"], qkv, 3 * D)
+            normed_gemv(w[o + "n1"], o + "qkv", qkv, 3 * D)
             if self.fused_attn:
                 # rotary + cache append + attention in one launch; args 4 (pos_add) and 12 (slot) are set per step
                 steps.append((lib.hk_decode_attn_rope_bf16, [qkv, P(w["cos"]), P(w["sin"]), P(ws["pos0"]), 0, kc, vc,
@@ -135,10 +147,10 @@ class LlamaGenerator:
                 # arg 8 (n_keys) is set per step
                 steps.append((lib.hk_decode_attn_bf16, [q, kc, vc, P(ws["kbias"]) if masked else None, att, B, H, hd, 0, rows, rows],
                               _ATTN, "hk_decode_attn_bf16"))
-            gemv(att, w[o + "o"], x, D, D, residual=x, out_f32=True)
-            normed_gemv(w[o + "n2"], w[o + "gu"], act, 2 * I, act="swiglu")
-            gemv(act, w[o + "down"], x, D, I, residual=x, out_f32=True)
-        normed_gemv(w["norm"], w["lm_head"], P(ws["logits"]), V, out_f32=True, ldo=ws["logits"].stride(0))
+            gemv(att, o + "o", x, D, D, residual=x, out_f32=True)
+            normed_gemv(w[o + "n2"], o + "gu", act, 2 * I, act="swiglu")
+            gemv(act, o + "down", x, D, I, residual=x, out_f32=True)
+        normed_gemv(w["norm"], "lm_head", P(ws["logits"]), V, out_f32=True, ldo=ws["logits"].stride(0))
         steps.append((lib.hk_argmax_f32, [P(ws["logits"]), P(ws["tok"]), B, V, ws["logits"].stride(0)], _STATIC, "hk_argmax_f32"))
         return plan
 

@@ -41,7 +41,7 @@ class HkGemvDesc(C.Structure):
         ("x", C.c_void_p), ("W", C.c_void_p), ("out", C.c_void_p), ("residual", C.c_void_p),
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("out_f32", C.c_int32),
         ("ldx", C.c_int64), ("ldo", C.c_int64), ("act", C.c_int32), ("norm_eps", C.c_float),
-        ("norm_weight", C.c_void_p),
+        ("norm_weight", C.c_void_p), ("w_tiled", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

@@ -349,8 +349,22 @@ def rope_(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, H: int, head_
     return qkv
 
 
+def tile_gemv_weight(w: torch.Tensor) -> torch.Tensor:
+    """Row-major bf16 [N, K] -> hk_gemv_desc.w_tiled's block layout [ceil(N/16), K/64, 2, 64, 8] (rows past N zero).
+    A layout permutation done once at load time (torch as plumbing)."""
+    _need(w, torch.bfloat16, "w")
+    N, K = w.shape
+    if K % 64:
+        raise RuntimeError("tile_gemv_weight: K must be a multiple of 64")
+    R = (N + 15) // 16
+    if R * 16 != N:
+        w = torch.cat([w, torch.zeros((R * 16 - N, K), dtype=w.dtype, device=w.device)])
+    # [r, i, b, q, h, e] -> [r, b, h, q, i, e]
+    return w.view(R, 16, K // 64, 4, 2, 8).permute(0, 2, 4, 3, 1, 5).contiguous().view(R, K // 64, 2, 64, 8)
+
+
 def gemv_desc(x, W, out, M, N, K, *, ldx=None, ldo=None, residual=None, out_f32=False, act="none", norm_weight=None,
-              norm_eps=0.0) -> L.HkGemvDesc:
+              norm_eps=0.0, w_tiled=False) -> L.HkGemvDesc:
     """Descriptor of one hk_gemv_bf16 call on raw pointers (the decode plan builds these once)."""
     d = L.HkGemvDesc()
     d.x, d.W, d.out, d.residual = x, W, out, residual
@@ -359,6 +373,7 @@ def gemv_desc(x, W, out, M, N, K, *, ldx=None, ldo=None, residual=None, out_f32=
     d.ldx = K if ldx is None else ldx
     d.ldo = (N // 2 if act == "swiglu" else N) if ldo is None else ldo
     d.norm_weight, d.norm_eps = norm_weight, norm_eps
+    d.w_tiled, d.reserved = 1 if w_tiled else 0, 0
     return d
 
 

@@ -226,6 +226,11 @@ typedef struct hk_gemv_desc {
     /* fused LlamaRMSNorm (modeling_llama.py:57-75) of the input, M <= 4: x is then the fp32 residual stream [M, K] and the
      * operand is bf16(norm_weight * (x * rsqrt(mean(x^2) + norm_eps))), what hk_rmsnorm would have written; NULL = x is bf16 */
     const float* norm_weight;
+    /* 1: W is stored in 16-row x 64-element blocks, [ceil(N/16)][K/64][2][64][8] bf16 -- block (r, b) holds rows 16 r .. 16 r + 15
+     * (rows past N zero), elements 64 b .. 64 b + 63, as [half h][lane l = 16 q + i][8]: element 8 e of row 16 r + i at k =
+     * 64 b + 16 q + 8 h + e.  A wave then streams one contiguous region (a decode-only copy of the weights: HBM is large). */
+    int32_t w_tiled;
+    int32_t reserved;      /* 0 */
 } hk_gemv_desc;
 int hk_gemv_bf16(const hk_gemv_desc* d, void* stream);
 

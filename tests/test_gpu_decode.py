@@ -268,3 +268,20 @@ def test_generation_kv_cache_equals_a_longer_prefill():
         assert _rel(kc[layer], k_ref) < 2e-2
     # and the logits of the last decode step are those of the longer prefill's last position
     assert _rel(out["logits"][4], ref["logits"]) < 2e-2
+
+
+@pytest.mark.parametrize("M,N,K,act", [(1, 4096, 11008, "none"), (3, 32001, 256, "none"), (2, 1024, 256, "swiglu"), (16, 48, 64, "none")])
+def test_gemv_tiled_weight_layout_gives_the_row_major_bits(M, N, K, act):
+    import ctypes as C
+    from hawkeye_amd import lib as L
+    x, w = _rand((M, K), 21, 1.0, torch.bfloat16), _rand((N, K), 22, 0.05, torch.bfloat16)
+    wt = ops.tile_gemv_weight(w)
+    assert wt.shape == ((N + 15) // 16, K // 64, 2, 64, 8)
+    ld = (N + 3) // 4 * 4 if act == "none" else N // 2
+    outs = []
+    for W_, tiled in ((w, False), (wt, True)):
+        buf = torch.zeros((M, ld), dtype=torch.float32 if act == "none" else torch.bfloat16, device=DEV)
+        d = ops.gemv_desc(x.data_ptr(), W_.data_ptr(), buf.data_ptr(), M, N, K, ldo=ld, out_f32=(act == "none"), act=act, w_tiled=tiled)
+        L.check(L.load().hk_gemv_bf16(C.byref(d), torch.cuda.current_stream().cuda_stream), "hk_gemv_bf16")
+        outs.append(buf)
+    assert torch.equal(outs[0], outs[1])

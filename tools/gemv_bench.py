@@ -18,6 +18,9 @@ shapes = [("qkv", 12288, 4096, "none", True), ("o_proj", 4096, 4096, "res", Fals
 for name, N, K, kind, norm in shapes:
     nbuf = max(2, int(1.2e9 // (N * K * 2)))
     ws = [torch.randn((N, K), device=dev, dtype=torch.float32).mul_(0.02).to(torch.bfloat16) for _ in range(nbuf)]
+    TILED = os.environ.get("GEMV_TILED", "0") == "1"
+    if TILED:
+        ws = [ops.tile_gemv_weight(w) for w in ws]
     x32 = torch.randn((M, K), device=dev)
     xb = x32.to(torch.bfloat16)
     gamma = torch.ones(K, device=dev)
@@ -25,7 +28,7 @@ for name, N, K, kind, norm in shapes:
     out = torch.empty((M, N), device=dev, dtype=torch.float32 if kind in ("res", "f32") else torch.bfloat16)
     descs = []
     for w in ws:
-        kw = dict(out_f32=kind in ("res", "f32"), act="swiglu" if kind == "swiglu" else "none")
+        kw = dict(out_f32=kind in ("res", "f32"), act="swiglu" if kind == "swiglu" else "none", w_tiled=TILED)
         if kind == "res":
             kw["residual"] = res.data_ptr()
         if norm and M <= 4:
@@ -46,5 +49,5 @@ for name, N, K, kind, norm in shapes:
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / (reps * nbuf)
-    print(f"M={M} {name:8s} N={N:6d} K={K:6d} KS={os.environ.get('HK_GEMV_KS', 'auto'):>4s}: {us:7.1f} us  {N * K * 2 / us / 1e6:6.2f} TB/s", flush=True)
+    print(f"M={M} {name:8s} N={N:6d} K={K:6d} KS={os.environ.get('HK_GEMV_KS', 'auto'):>4s} tiled={int(TILED)}: {us:7.1f} us  {N * K * 2 / us / 1e6:6.2f} TB/s", flush=True)
     del ws
