@@ -68,6 +68,11 @@ struct GemmParams {
     // fp32 partial product to C + z * split_stride, slice 0 carries bias and residual
     int ksplit, kper;
     int64_t split_stride;
+    // hk_gemm_desc.w_tiled: W in 64 x 64 blocks, [N/64][K/64][64][64].  wrow(n) = element offset of row n's first K-tile, wk =
+    // elements from one K-tile of a row to the next (row-major: n * ldw and 64)
+    int wt, wnkt;
+    __device__ __forceinline__ int64_t wrow(int n) const { return wt ? ((int64_t)(n >> 6) * wnkt * 4096 + (n & 63) * 64) : (int64_t)n * ldw; }
+    __device__ __forceinline__ int wk() const { return wt ? 4096 : 64; }
 };
 
 // Exact-erf GELU (nn.GELU default, vit.py:44; ACT2FN["gelu"], Qformer.py:383) to fp32 rounding noise:
@@ -687,7 +692,7 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
                 go[kind][i] = (uint32_t)((p.a.off(m) + sw) * 2);
             } else {
                 const int n = min(t0 + (kind - 2) * 128 + row, p.N - 1);
-                go[kind][i] = (uint32_t)(((int64_t)n * p.ldw + sw) * 2);
+                go[kind][i] = (uint32_t)((p.wrow(n) + sw) * 2);
             }
         }
     };
@@ -695,7 +700,7 @@ __global__ __launch_bounds__(512) void hk_gemm_pp_kernel(const GemmParams p) {
         if (s_tile[kind] >= ntile) return false;
         __bf16* dst = lds + s_par[kind] * BUF + kind * HALF + wave * 8 * BK;
         // scalar base (operand + K offset) + the piece's 32-bit lane offset: no 64-bit vector address per piece
-        const __bf16* kb = (kind < 2 ? p.A : p.W) + s_k[kind] * BK;
+        const __bf16* kb = kind < 2 ? p.A + s_k[kind] * BK : p.W + s_k[kind] * p.wk();
         glds16_s(kb, go[kind][0], dst);
         if constexpr (NI == 4) glds16_s(kb, go[kind][1], dst + 64 * BK);
         else glds16_s(kb, go[kind][1], dst + ((kind < 2 && (8 + wave) * 8 >= AH) ? 32 : 64) * BK);
@@ -1179,16 +1184,16 @@ __global__ __launch_bounds__(WM* WN * 64) void hk_gemm_kernel(const GemmParams p
     for (int i = 0; i < B_IT; ++i) {
         const int row = (i * NW + wave) * 8 + lrow;
         const int n = min(n0 + row, p.N - 1);
-        bptr[i] = p.W + (int64_t)n * p.ldw + ((lpc ^ ((row >> 1) & 7)) << 3) + kt0 * BK;
+        bptr[i] = p.W + p.wrow(n) + ((lpc ^ ((row >> 1) & 7)) << 3) + (int64_t)kt0 * p.wk();
     }
     auto stage_load = [&](int stage, int kt) {
         __bf16* As = lds + stage * STAGE;
         __bf16* Bs = As + BM * BK;
-        const int k0 = kt * BK;
+        const int k0 = kt * BK, k0w = kt * p.wk();
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) glds16(aptr[i] + k0, As + (i * NW + wave) * 8 * BK);
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) glds16(bptr[i] + k0, Bs + (i * NW + wave) * 8 * BK);
+        for (int i = 0; i < B_IT; ++i) glds16(bptr[i] + k0w, Bs + (i * NW + wave) * 8 * BK);
     };
 
     // ---- fragment read offsets (elements): row (lane & 15), logical chunk kk*4 + (lane >> 4) ----
@@ -1484,6 +1489,8 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
 
     GemmParams p;
     p.A = reinterpret_cast<const __bf16*>(d->A);
+    HK_REQUIRE(d->w_tiled == 0 || (d->w_tiled == 1 && d->N % 64 == 0 && d->K % 64 == 0),
+               "hk_gemm_bf16: w_tiled needs N=%d and K=%d to be multiples of 64", d->N, d->K);
     p.W = reinterpret_cast<const __bf16*>(d->W);
     p.bias = d->bias;
     p.res = d->residual;
@@ -1498,6 +1505,8 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
     p.c = RowMap{d->c_rows.ld, d->c_rows.rows_per_batch, d->c_rows.batch_stride};
     p.r = RowMap{d->r_rows.ld, d->r_rows.rows_per_batch, d->r_rows.batch_stride};
     p.ldw = d->ldw;
+    p.wt = d->w_tiled;
+    p.wnkt = d->K / 64;
     p.act = d->act;
     p.out_f32 = d->out_dtype == HK_DT_F32;
     p.res_bf16 = d->res_dtype == HK_DT_BF16;
@@ -1652,7 +1661,7 @@ extern "C" int hk_gemm_bf16(const hk_gemm_desc* d, void* stream) {
         // HK_GEMM_DUO: bit e set = epilogue kind e runs on the two-workgroups-per-CU 256x128 kernel (hk_gemm_duo_kernel)
         // instead of the 256x256 one (A/B switch; the default is what measured faster per epilogue kind)
         const int duo = duo_mask().load(std::memory_order_relaxed);
-        const bool use_duo = epi != 5 && ((duo >> epi) & 1) != 0 && p.K >= 128 && d->N % 128 == 0 && d->a_rows.rows_per_batch == 0 &&
+        const bool use_duo = epi != 5 && p.wt == 0 && ((duo >> epi) & 1) != 0 && p.K >= 128 && d->N % 128 == 0 && d->a_rows.rows_per_batch == 0 &&
                              p.M >= 256;
         if (use_duo && p.M % 256 != 0) {
             // the duo kernel addresses whole 256-row tiles through scalar bases: leftover rows join (or become) the tail launch

@@ -32,7 +32,7 @@ class HkGemmDesc(C.Structure):
         ("act", C.c_int32), ("out_dtype", C.c_int32), ("res_dtype", C.c_int32), ("scale_cols", C.c_int32),
         ("scale", C.c_float),
         ("row_stats", C.c_void_p), ("col_c", C.c_void_p), ("row_part", C.c_void_p),
-        ("split_k", C.c_int32), ("split_stride", C.c_int64),
+        ("split_k", C.c_int32), ("w_tiled", C.c_int32), ("split_stride", C.c_int64),
     ]
 
 

@@ -89,6 +89,9 @@ class LlamaPrefill:
         self.pool = _Pool(self.device)
         self.plans: "OrderedDict[Tuple[int, int, bool, bool], _Plan]" = OrderedDict()   # (B, S, masked, explicit position ids)
         self.last_ws: Dict[str, torch.Tensor] = {}
+        # projection weights streamed from a 64 x 64-block copy (hk_gemm_desc.w_tiled): HK_LLM_TILED=0 = row-major (A/B aid)
+        self.tiled = os.environ.get("HK_LLM_TILED", "1") != "0"
+        self.w64: Dict[int, torch.Tensor] = {}
 
     def pooled_bytes(self) -> int:
         return self.pool.nbytes()
@@ -142,7 +145,8 @@ class LlamaPrefill:
             inv_freq = 1.0 / (cfg.rope_base ** (torch.arange(0, hd, 2).float() / hd))
             freqs = torch.einsum("i,j->ij", torch.arange(cfg.max_position_embeddings, dtype=inv_freq.dtype), inv_freq)
             w["cos"], w["sin"] = freqs.cos().to(dev).contiguous(), freqs.sin().to(dev).contiguous()
-        self.w = w
+        self.w, self.w64 = w, {}
+        self.plans.clear()
         return self
 
     def init_random(self, seed: int = 0, std: float = 0.02):
@@ -169,7 +173,8 @@ class LlamaPrefill:
             inv_freq = 1.0 / (cfg.rope_base ** (torch.arange(0, hd, 2).float() / hd))
             freqs = torch.einsum("i,j->ij", torch.arange(cfg.max_position_embeddings, dtype=inv_freq.dtype), inv_freq)
             w["cos"], w["sin"] = freqs.cos().to(dev).contiguous(), freqs.sin().to(dev).contiguous()
-        self.w = w
+        self.w, self.w64 = w, {}
+        self.plans.clear()
         return self
 
     # ------------------------------------------------------------------ plan
@@ -188,8 +193,21 @@ class LlamaPrefill:
                 return s
         return 1
 
+    def _tiled(self, W: torch.Tensor):
+        """(tensor to stream, w_tiled flag) for a packed projection weight: its 64 x 64-block copy when HK_LLM_TILED is on
+        (hk_gemm_desc.w_tiled; made on first use, kept beside the row-major tensor the decode tiling and tests read)."""
+        if not self.tiled or W.shape[0] % 64 or W.shape[1] % 64:
+            return W, False
+        key = W.data_ptr()
+        t = self.w64.get(key)
+        if t is None:
+            with torch.cuda.device(self.device):
+                t = self.w64[key] = ops.tile_gemm_weight(W)
+        return t, True
+
     def _gemm(self, plan, A, W, Cout, M, N, K, **kw):
-        d = ops.gemm_desc(A, W.data_ptr(), Cout, M, N, K, a_rows=(K, 0, 0), c_rows=(N, 0, 0), **kw)
+        W, tiled = self._tiled(W) if M > 16 else (W, False)       # lm_head on B rows stays row-major
+        d = ops.gemm_desc(A, W.data_ptr(), Cout, M, N, K, a_rows=(K, 0, 0), c_rows=(N, 0, 0), w_tiled=tiled, **kw)
         plan.keep.append(d)
         plan.steps.append((self.lib.hk_gemm_bf16, (C.byref(d),), "hk_gemm_bf16"))
 
@@ -256,8 +274,9 @@ class LlamaPrefill:
             norm(w[o + "n2"], sk_o)
             if self.fused_swiglu:
                 # gate | up projections and silu(gate) * up in one launch: the [M, 2I] matrix is never written
-                d = ops.gemm_desc(P(xn), w[o + "gu"].data_ptr(), P(act), M, 2 * I, D, a_rows=(D, 0, 0), c_rows=(I, 0, 0),
-                                  act=L.HK_ACT_SWIGLU)
+                wgu, tl = self._tiled(w[o + "gu"])
+                d = ops.gemm_desc(P(xn), wgu.data_ptr(), P(act), M, 2 * I, D, a_rows=(D, 0, 0), c_rows=(I, 0, 0),
+                                  act=L.HK_ACT_SWIGLU, w_tiled=tl)
                 plan.keep.append(d)
                 plan.steps.append((self.lib.hk_gemm_bf16, (C.byref(d),), "hk_gemm_bf16"))
             else:

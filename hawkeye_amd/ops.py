@@ -32,7 +32,7 @@ def _need(t: torch.Tensor, dtype, name: str):
 def gemm_desc(A, W, C_out, M, N, K, *, bias=None, residual=None, a_rows: Rows, c_rows: Rows,
               r_rows: Rows = (0, 0, 0), ldw=None, act=L.HK_ACT_NONE, out_f32=False, res_bf16=False,
               scale_cols=0, scale=1.0, row_stats=None, col_c=None, row_part=None, split_k=0,
-              split_stride=0) -> L.HkGemmDesc:
+              split_stride=0, w_tiled=False) -> L.HkGemmDesc:
     """Raw-pointer descriptor; A/W/C_out/bias/residual (and row_stats/col_c: LayerNorm of A folded into the GEMM,
     see include/hawkeye_hip.h) are integer device addresses."""
     d = L.HkGemmDesc()
@@ -49,7 +49,17 @@ def gemm_desc(A, W, C_out, M, N, K, *, bias=None, residual=None, a_rows: Rows, c
     d.scale = scale
     d.row_stats, d.col_c, d.row_part = row_stats, col_c, row_part
     d.split_k, d.split_stride = split_k, split_stride
+    d.w_tiled = 1 if w_tiled else 0
     return d
+
+
+def tile_gemm_weight(w: torch.Tensor) -> torch.Tensor:
+    """Row-major bf16 [N, K] -> hk_gemm_desc.w_tiled's layout [N/64, K/64, 64, 64].  A permutation done once at load time."""
+    _need(w, torch.bfloat16, "w")
+    N, K = w.shape
+    if N % 64 or K % 64:
+        raise RuntimeError("tile_gemm_weight: N and K must be multiples of 64")
+    return w.view(N // 64, 64, K // 64, 64).permute(0, 2, 1, 3).contiguous()
 
 
 def run_gemm(d: L.HkGemmDesc):
@@ -61,14 +71,20 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
            scale_cols: int = 0, scale: float = 1.0, out: Optional[torch.Tensor] = None,
            row_stats: Optional[torch.Tensor] = None, col_c: Optional[torch.Tensor] = None,
            row_part: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out = act((x @ w.T + bias) * colscale) + residual; x [M,K] bf16, w [N,K] bf16.
+    """out = act((x @ w.T + bias) * colscale) + residual; x [M,K] bf16, w [N,K] bf16 (or tile_gemm_weight's 4-D layout).
     row_stats [M,2] fp32 + col_c [N] fp32: LayerNorm of x folded into the GEMM (w, bias prepared by fold_layernorm)."""
     _need(x, torch.bfloat16, "x")
     _need(w, torch.bfloat16, "w")
     M, K = x.shape
-    N = w.shape[0]
-    if x.stride(1) != 1 or w.stride(1) != 1 or w.shape[1] != K:
-        raise RuntimeError("linear: x and w must be K-contiguous with matching K")
+    tiled = w.dim() == 4      # tile_gemm_weight's [N/64, K/64, 64, 64]
+    if tiled:
+        if tuple(w.shape[2:]) != (64, 64) or not w.is_contiguous() or w.shape[1] * 64 != K or x.stride(1) != 1:
+            raise RuntimeError("linear: a tiled w must be contiguous [N/64, K/64, 64, 64] with matching K")
+        N = w.shape[0] * 64
+    else:
+        N = w.shape[0]
+        if x.stride(1) != 1 or w.stride(1) != 1 or w.shape[1] != K:
+            raise RuntimeError("linear: x and w must be K-contiguous with matching K")
     if bias is not None:
         _need(bias, torch.float32, "bias")
     if residual is not None:
@@ -89,8 +105,8 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     _need(out, out_dtype, "out")
     d = gemm_desc(x.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, K, bias=_ptr(bias), residual=_ptr(residual),
                   a_rows=(x.stride(0), 0, 0), c_rows=(out.stride(0), 0, 0),
-                  r_rows=(residual.stride(0), 0, 0) if residual is not None else (0, 0, 0), ldw=w.stride(0),
-                  act={"gelu": L.HK_ACT_GELU_ERF, "swiglu": L.HK_ACT_SWIGLU}.get(act, L.HK_ACT_NONE), out_f32=out_dtype == torch.float32,
+                  r_rows=(residual.stride(0), 0, 0) if residual is not None else (0, 0, 0), ldw=K if tiled else w.stride(0),
+                  w_tiled=tiled, act={"gelu": L.HK_ACT_GELU_ERF, "swiglu": L.HK_ACT_SWIGLU}.get(act, L.HK_ACT_NONE), out_f32=out_dtype == torch.float32,
                   res_bf16=residual is not None and residual.dtype == torch.bfloat16,
                   scale_cols=scale_cols, scale=scale)
     if row_stats is not None:

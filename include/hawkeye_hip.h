@@ -93,6 +93,11 @@ typedef struct hk_gemm_desc {
      * (elements); slice 0 carries bias and residual.  The consumer sums the slices (hk_layernorm_parts).  Needs fp32
      * output, no activation, no folded LayerNorm, no row_part.  0 or 1 = off. */
     int32_t split_k;
+    /* 1: W is stored in 64 x 64 blocks, [N/64][K/64][64 rows][64 elements] bf16 (element k of row n at
+     * ((n / 64) * (K / 64) + k / 64) * 4096 + (n % 64) * 64 + k % 64; ldw is ignored): a workgroup's weight tile is whole 8 KB
+     * pieces and its walk over K contiguous, which is what weights that arrive cold from HBM want (the LLM's, read once per
+     * pass).  N and K multiples of 64.  0: row-major with row stride ldw. */
+    int32_t w_tiled;
     int64_t split_stride;
 } hk_gemm_desc;
 

@@ -547,3 +547,19 @@ def test_gemm_two_workgroups_per_cu_kernel_gives_the_256x256_kernels_bits(kind):
             lib.hk_gemm_duo_mask(0)
     finally:
         lib.hk_gemm_duo_mask(0)
+
+
+# hk_gemm_desc.w_tiled: the same GEMM with W in 64 x 64 blocks -- every kernel family the LLM's shapes reach (persistent 256- and
+# 192-row tiles, multi-stage 192x192 / 192x128 / 256x128 / 128x128 three- and four-stage, split launches with a tail)
+@pytest.mark.parametrize("M,N,K,act,f32", [(2816, 12288, 4096, "none", False), (2816, 4096, 4096, "none", True), (2816, 22016, 4096, "swiglu", False),
+                                           (352, 12288, 4096, "none", False), (352, 22016, 4096, "swiglu", False), (352, 4096, 11008, "none", True),
+                                           (704, 4096, 4096, "none", True), (1408, 4096, 11008, "none", True), (96, 768, 256, "none", False),
+                                           (5000, 1024, 512, "none", False)])
+def test_gemm_tiled_weight_layout_gives_the_row_major_bits(M, N, K, act, f32):
+    x, w = _rand((M, K), 31, 1.0, torch.bfloat16), _rand((N, K), 32, 0.03, torch.bfloat16)
+    wt = ops.tile_gemm_weight(w)
+    kw = dict(act=act, out_dtype=torch.float32 if f32 else torch.bfloat16)
+    res = _rand((M, N), 33) if f32 else None
+    a = ops.linear(x, w, residual=res, **kw)
+    b = ops.linear(x, wt, residual=res, **kw)
+    assert torch.equal(a, b)
