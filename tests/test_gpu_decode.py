@@ -285,3 +285,32 @@ def test_gemv_tiled_weight_layout_gives_the_row_major_bits(M, N, K, act):
         L.check(L.load().hk_gemv_bf16(C.byref(d), torch.cuda.current_stream().cuda_stream), "hk_gemv_bf16")
         outs.append(buf)
     assert torch.equal(outs[0], outs[1])
+
+
+def test_generation_routes_agree(monkeypatch):
+    """inputs_embeds (what answer() passes, tasks/test.py:121-122) vs src + video; tiled vs row-major decode weights; fused vs
+    separate rope / norm launches: the same tokens, and bit-identical logits where only the weight layout or the launch split differs."""
+    from hawkeye_amd.llm import LlamaPrefill
+    from hawkeye_amd.decode import LlamaGenerator
+    from oracle import llama_prefill_oracle as LO
+    cfg = SMALL_LLM
+    sd = W.make_llm_state_dict(cfg, 9)
+    pre = LlamaPrefill(cfg, DEV).load_state_dict(sd)
+    src, _ = W.make_prompt(cfg, 2, 56, 8, 9, ragged=False)
+    video = W._normal("video_tokens", 9, (16, cfg.hidden_size), 0.05)
+    emb = LO.embed_splice(sd, src, video).to(DEV)
+    src, video = src.to(DEV), video.to(DEV)
+    base = LlamaGenerator(pre).generate(src=src, video=video, max_new_tokens=6, return_logits=True)
+    via_emb = LlamaGenerator(pre).generate(inputs_embeds=emb, max_new_tokens=6, return_logits=True)
+    assert torch.equal(base["tokens"], via_emb["tokens"]) and _rel(via_emb["logits"], base["logits"]) < 1e-2
+    monkeypatch.setenv("HK_DECODE_TILED", "0")
+    rowmajor = LlamaGenerator(pre).generate(src=src, video=video, max_new_tokens=6, return_logits=True)
+    assert torch.equal(rowmajor["logits"], base["logits"]) and torch.equal(rowmajor["tokens"], base["tokens"])
+    monkeypatch.delenv("HK_DECODE_TILED")
+    monkeypatch.setenv("HK_DECODE_FUSED_ATTN", "0")
+    split = LlamaGenerator(pre).generate(src=src, video=video, max_new_tokens=6, return_logits=True)
+    assert torch.equal(split["logits"], base["logits"])
+    monkeypatch.delenv("HK_DECODE_FUSED_ATTN")
+    monkeypatch.setenv("HK_DECODE_FUSED_NORM", "0")
+    unfused = LlamaGenerator(pre).generate(src=src, video=video, forced_tokens=base["tokens"], max_new_tokens=6, return_logits=True)
+    assert _rel(unfused["logits"], base["logits"]) < 1e-2
