@@ -314,3 +314,40 @@ def test_generation_routes_agree(monkeypatch):
     monkeypatch.setenv("HK_DECODE_FUSED_NORM", "0")
     unfused = LlamaGenerator(pre).generate(src=src, video=video, forced_tokens=base["tokens"], max_new_tokens=6, return_logits=True)
     assert _rel(unfused["logits"], base["logits"]) < 1e-2
+
+
+def test_generator_pool_survives_changing_shapes():
+    """Prompt length, batch size and token budget change from call to call (an eval run): the pooled caches / plans of one
+    generator give the same tokens and logits as a fresh generator for each call, in any order, incl. 16 sequences (the
+    unfused-norm route) and a left-padded batch."""
+    from hawkeye_amd.llm import LlamaPrefill
+    from hawkeye_amd.decode import LlamaGenerator
+    cfg = SMALL_LLM
+    pre = LlamaPrefill(cfg, DEV).load_state_dict(W.make_llm_state_dict(cfg, 11))
+    shared = LlamaGenerator(pre)
+    cases = [(1, 40, 5, False), (16, 72, 9, False), (3, 130, 4, True), (1, 40, 5, False), (2, 200, 30, False), (3, 60, 70, True)]
+    for B, S, T, masked in cases:
+        src, _ = W.make_prompt(cfg, B, S, 8, 11 + B, ragged=False)
+        video = W._normal("video_tokens", 11, (B * 8, cfg.hidden_size), 0.05).to(DEV)
+        mask = None
+        if masked:
+            mask = torch.ones(B, S, dtype=torch.int64)
+            for b in range(B):
+                n_pad = 3 * b
+                mask[b, :n_pad] = 0
+                src[b] = torch.roll(src[b], n_pad)
+                src[b, :n_pad] = 2
+            mask = mask.to(DEV)
+        src = src.to(DEV)
+        a = shared.generate(src=src, video=video, attention_mask=mask, max_new_tokens=T, return_logits=True)
+        b_ = LlamaGenerator(pre).generate(src=src, video=video, attention_mask=mask, max_new_tokens=T, return_logits=True)
+        assert torch.equal(a["tokens"], b_["tokens"]) and torch.equal(a["logits"], b_["logits"]), (B, S, T)
+        assert a["tokens"].shape == (B, T)
+    with pytest.raises(RuntimeError, match="at most 16"):
+        shared.generate(src=torch.zeros((17, 8), dtype=torch.int64, device=DEV), max_new_tokens=2)
+    with pytest.raises(RuntimeError, match="max_position_embeddings"):
+        shared.generate(src=torch.zeros((1, 250), dtype=torch.int64, device=DEV), max_new_tokens=10)
+    with pytest.raises(RuntimeError, match="LEFT-padded"):
+        m = torch.ones((1, 8), dtype=torch.int64, device=DEV)
+        m[0, -1] = 0
+        shared.generate(src=torch.zeros((1, 8), dtype=torch.int64, device=DEV), attention_mask=m, max_new_tokens=2)
