@@ -300,6 +300,11 @@ struct DecodeAttnParams {
     float qscale;
     int H, n_keys;
     int64_t cache_rows, bias_stride;
+    // key split (long caches, few (sequence, head) pairs): grid.z = nsplit slices of `chunk` keys; slice s leaves its
+    // un-normalised output row, its maximum and its sum in part[((b * H + head) * nsplit + s) * (HD + 2) ...] and
+    // hk_decode_attn_combine_kernel merges them; nsplit = 1: the workgroup writes the normalised bf16 row itself
+    int nsplit, chunk;
+    float* part;
 };
 
 template <int HD, int NT, bool FUSED>
@@ -314,9 +319,10 @@ __global__ __launch_bounds__(NT) void hk_decode_attn_kernel(const DecodeAttnPara
     const int sub = tid % LPK, g = tid / LPK;
     const int head = blockIdx.x, b = blockIdx.y;
     const int D = p.H * HD;
-    const int n_keys = p.n_keys;
-    const __bf16* kb = p.kc + (int64_t)b * p.cache_rows * D + head * HD + sub * 8;
-    const __bf16* vb = p.vc + (int64_t)b * p.cache_rows * D + head * HD + sub * 8;
+    const int k_begin = p.nsplit > 1 ? (int)blockIdx.z * p.chunk : 0;
+    const int n_keys = p.nsplit > 1 ? min(p.chunk, p.n_keys - k_begin) : p.n_keys;     // this workgroup's keys: [k_begin, k_begin + n_keys)
+    const __bf16* kb = p.kc + ((int64_t)b * p.cache_rows + k_begin) * D + head * HD + sub * 8;
+    const __bf16* vb = p.vc + ((int64_t)b * p.cache_rows + k_begin) * D + head * HD + sub * 8;
     float qf[8];
     if constexpr (FUSED) {
         constexpr int half = HD / 2;
@@ -329,9 +335,11 @@ __global__ __launch_bounds__(NT) void hk_decode_attn_kernel(const DecodeAttnPara
             const float k1 = (float)row[D + tid], k2 = (float)row[D + tid + half];
             qs[tid] = (float)(__bf16)((q1 * c - q2 * s) * p.qscale);
             qs[tid + half] = (float)(__bf16)((q2 * c + q1 * s) * p.qscale);
-            p.kc[crow + tid] = (__bf16)(k1 * c - k2 * s);
-            p.kc[crow + tid + half] = (__bf16)(k2 * c + k1 * s);
-        } else if (tid < half + HD / 8) {
+            if (p.slot >= k_begin && p.slot < k_begin + n_keys) {   // the slice that holds the new row writes it; no other slice reads it
+                p.kc[crow + tid] = (__bf16)(k1 * c - k2 * s);
+                p.kc[crow + tid + half] = (__bf16)(k2 * c + k1 * s);
+            }
+        } else if (tid < half + HD / 8 && p.slot >= k_begin && p.slot < k_begin + n_keys) {
             const int j = (tid - half) * 8;
             *reinterpret_cast<u32x4*>(p.vc + crow + j) = *reinterpret_cast<const u32x4*>(row + 2 * D + j);
         }
@@ -346,7 +354,7 @@ __global__ __launch_bounds__(NT) void hk_decode_attn_kernel(const DecodeAttnPara
             qf[2 * k + 1] = bf16_hi(u[k]);
         }
     }
-    const float* bias = p.key_bias ? p.key_bias + (int64_t)b * p.bias_stride : nullptr;
+    const float* bias = p.key_bias ? p.key_bias + (int64_t)b * p.bias_stride + k_begin : nullptr;
     // ---- scores ----
     constexpr int U = 4;
     for (int k0 = g; k0 < n_keys; k0 += U * NG) {
@@ -420,6 +428,19 @@ __global__ __launch_bounds__(NT) void hk_decode_attn_kernel(const DecodeAttnPara
         for (int k = 0; k < 8; ++k) obuf[wave][lane * 8 + k] = acc[k];
     }
     __syncthreads();
+    if (p.nsplit > 1) {
+        float* pr = p.part + (((int64_t)b * p.H + head) * p.nsplit + blockIdx.z) * (HD + 2);
+        if (tid < HD) {
+            float o = obuf[0][tid];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) o += obuf[w][tid];
+            pr[tid] = o;
+        } else if (tid == HD) {
+            pr[HD] = mx;
+            pr[HD + 1] = sum;
+        }
+        return;
+    }
     if (tid < HD / 2) {
         const int d = tid * 2;
         const float inv = 1.0f / sum;
@@ -431,6 +452,23 @@ __global__ __launch_bounds__(NT) void hk_decode_attn_kernel(const DecodeAttnPara
         }
         *reinterpret_cast<uint32_t*>(p.out + (int64_t)b * D + head * HD + d) = pack_bf16x2(o0 * inv, o1 * inv);
     }
+}
+
+// Merge of the key slices of hk_decode_attn_kernel: out = sum_s o_s 2^(m_s - M) / sum_s l_s 2^(m_s - M), slices in order.
+template <int HD>
+__global__ __launch_bounds__(HD) void hk_decode_attn_combine_kernel(const float* __restrict__ part, __bf16* __restrict__ out, int H,
+                                                                    int nsplit) {
+    const int head = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+    const float* pr = part + ((int64_t)b * H + head) * nsplit * (HD + 2);
+    float M = pr[HD];
+    for (int s = 1; s < nsplit; ++s) M = fmaxf(M, pr[s * (HD + 2) + HD]);
+    float o = 0.f, l = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float w = __builtin_amdgcn_exp2f(pr[s * (HD + 2) + HD] - M);
+        o += pr[s * (HD + 2) + d] * w;
+        l += pr[s * (HD + 2) + HD + 1] * w;
+    }
+    out[((int64_t)b * H + head) * HD + d] = (__bf16)(o / l);
 }
 
 // Greedy next token (do_sample=False, num_beams=1: tasks/test.py:525, test_recursive_grounding.py:298): index of the
@@ -569,13 +607,27 @@ namespace {
 template <int HD, int NT, bool FUSED>
 int launch_decode_attn(const DecodeAttnParams& p, int B, hipStream_t s) {
     static std::atomic<unsigned long long> done{0};
-    const size_t lds = (size_t)p.n_keys * sizeof(float);
+    const size_t lds = (size_t)(p.nsplit > 1 ? p.chunk : p.n_keys) * sizeof(float);
     if (lds > 32 * 1024) {
         const hipError_t e = hk_lds_attr_once(done, reinterpret_cast<const void*>(&hk_decode_attn_kernel<HD, NT, FUSED>), 60 * 1024);
         HK_REQUIRE(e == hipSuccess, "hk_decode_attn: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL((hk_decode_attn_kernel<HD, NT, FUSED>), dim3((unsigned)p.H, (unsigned)B), dim3(NT), lds, s, p);
+    hipLaunchKernelGGL((hk_decode_attn_kernel<HD, NT, FUSED>), dim3((unsigned)p.H, (unsigned)B, (unsigned)p.nsplit), dim3(NT), lds, s, p);
+    if (p.nsplit > 1)
+        hipLaunchKernelGGL((hk_decode_attn_combine_kernel<HD>), dim3((unsigned)p.H, (unsigned)B), dim3(HD), 0, s, p.part, p.out, p.H, p.nsplit);
     return HK_OK;
+}
+// slices of whole 64-key tiles, none empty; 1 = no split
+void set_key_split(DecodeAttnParams& p, int key_splits, float* ws) {
+    p.nsplit = 1;
+    p.chunk = 0;
+    p.part = ws;
+    if (key_splits > 1 && ws != nullptr && p.n_keys >= 128) {
+        const int want = key_splits < 16 ? key_splits : 16;
+        const int chunk = ((p.n_keys + want - 1) / want + 63) / 64 * 64;
+        p.chunk = chunk;
+        p.nsplit = (p.n_keys + chunk - 1) / chunk;
+    }
 }
 template <bool FUSED>
 int dispatch_decode_attn(const DecodeAttnParams& p, int B, int head_dim, hipStream_t s) {
@@ -589,7 +641,7 @@ int dispatch_decode_attn(const DecodeAttnParams& p, int B, int head_dim, hipStre
 
 extern "C" int hk_decode_attn_bf16(const void* q, const void* k_cache, const void* v_cache, const float* key_bias, void* out,
                                    int32_t B, int32_t H, int32_t head_dim, int32_t n_keys, int64_t cache_rows,
-                                   int64_t bias_stride, void* stream) {
+                                   int64_t bias_stride, int32_t key_splits, float* split_ws, void* stream) {
     HK_REQUIRE(q && k_cache && v_cache && out, "hk_decode_attn_bf16: null pointer");
     HK_REQUIRE(B > 0 && B < 65536 && H > 0 && (head_dim == 64 || head_dim == 128), "hk_decode_attn_bf16: bad shape B=%d H=%d head_dim=%d",
                B, H, head_dim);
@@ -608,6 +660,7 @@ extern "C" int hk_decode_attn_bf16(const void* q, const void* k_cache, const voi
     p.n_keys = n_keys;
     p.cache_rows = cache_rows;
     p.bias_stride = bias_stride;
+    set_key_split(p, key_splits, split_ws);
     const int rc = dispatch_decode_attn<false>(p, B, head_dim, reinterpret_cast<hipStream_t>(stream));
     if (rc != HK_OK) return rc;
     HK_CHECK_LAUNCH("hk_decode_attn_bf16");
@@ -617,7 +670,7 @@ extern "C" int hk_decode_attn_bf16(const void* q, const void* k_cache, const voi
 extern "C" int hk_decode_attn_rope_bf16(const void* qkv, const float* cos_table, const float* sin_table, const int32_t* pos0,
                                         int32_t pos_add, void* k_cache, void* v_cache, const float* key_bias, void* out, int32_t B,
                                         int32_t H, int32_t head_dim, int32_t slot, int64_t cache_rows, int64_t bias_stride,
-                                        int32_t table_rows, float q_scale, void* stream) {
+                                        int32_t table_rows, float q_scale, int32_t key_splits, float* split_ws, void* stream) {
     HK_REQUIRE(qkv && cos_table && sin_table && pos0 && k_cache && v_cache && out, "hk_decode_attn_rope_bf16: null pointer");
     HK_REQUIRE(B > 0 && B < 65536 && H > 0 && (head_dim == 64 || head_dim == 128),
                "hk_decode_attn_rope_bf16: bad shape B=%d H=%d head_dim=%d", B, H, head_dim);
@@ -645,6 +698,7 @@ extern "C" int hk_decode_attn_rope_bf16(const void* qkv, const float* cos_table,
     p.n_keys = slot + 1;
     p.cache_rows = cache_rows;
     p.bias_stride = bias_stride;
+    set_key_split(p, key_splits, split_ws);
     const int rc = dispatch_decode_attn<true>(p, B, head_dim, reinterpret_cast<hipStream_t>(stream));
     if (rc != HK_OK) return rc;
     HK_CHECK_LAUNCH("hk_decode_attn_rope_bf16");

@@ -55,6 +55,8 @@ class LlamaGenerator:
         self.fused_attn = os.environ.get("HK_DECODE_FUSED_ATTN", "1") != "0"
         # HK_DECODE_FUSED_NORM=0: every RMSNorm as its own launch (A/B aid)
         self.fused_norm = os.environ.get("HK_DECODE_FUSED_NORM", "1") != "0"
+        # HK_DECODE_KEY_SPLIT=0: one workgroup per (sequence, head) whatever the cache length (A/B aid)
+        self.key_split = os.environ.get("HK_DECODE_KEY_SPLIT", "1") != "0"
         # Decode-only copy of the projection weights in hk_gemv_desc.w_tiled's block layout: a wave streams one contiguous
         # region instead of 16 rows 8-22 KB apart (cold-weight sweep, row-major -> tiled: gate|up 39.5 -> 31.1 us = 5.8 TB/s,
         # down_proj 21.0 -> 16.8, qkv 21.9 -> 18.9, lm_head 55 -> 43 = 6.1 TB/s).  Costs the weights' size again (13.5 GB for
@@ -111,6 +113,10 @@ class LlamaGenerator:
         x, xn, qkv, q, att, act = (P(ws[k]) for k in ("x", "xn", "qkv", "q", "att", "act"))
         qscale = (hd ** -0.5) * LOG2E
         steps, lib = plan.steps, self.lib
+        # long caches with few (sequence, head) pairs: the keys of one head go to several workgroups + a merge launch
+        # (hk_decode_attn_*'s key_splits; pays from ~1000 keys on: a 1500-token prompt 3.7 -> see profiles/r03_decode.jsonl)
+        ksplit = min(8, rows // 512) if (self.key_split and B * H <= 512) else 1
+        part = P(self.pool.view("attn_part", (B * H * max(ksplit, 1) * (hd + 2),), f32)) if ksplit > 1 else None
 
         def gemv(xp, name, out, N, K, **kw):
             W = self.wt[name] if self.tiled else w[name]
@@ -139,14 +145,15 @@ class LlamaGenerator:
                 # rotary + cache append + attention in one launch; args 4 (pos_add) and 12 (slot) are set per step
                 steps.append((lib.hk_decode_attn_rope_bf16, [qkv, P(w["cos"]), P(w["sin"]), P(ws["pos0"]), 0, kc, vc,
                                                              P(ws["kbias"]) if masked else None, att, B, H, hd, 0, rows, rows,
-                                                             cfg.max_position_embeddings, qscale], _FUSED, "hk_decode_attn_rope_bf16"))
+                                                             cfg.max_position_embeddings, qscale, ksplit, part], _FUSED,
+                              "hk_decode_attn_rope_bf16"))
             else:
                 # args 4 (pos_add) and 11 (slot) are set per step
                 steps.append((lib.hk_decode_rope_append, [qkv, P(w["cos"]), P(w["sin"]), P(ws["pos0"]), 0, q, kc, vc, B, H, hd, 0, rows,
                                                           cfg.max_position_embeddings, qscale], _ROPE, "hk_decode_rope_append"))
                 # arg 8 (n_keys) is set per step
-                steps.append((lib.hk_decode_attn_bf16, [q, kc, vc, P(ws["kbias"]) if masked else None, att, B, H, hd, 0, rows, rows],
-                              _ATTN, "hk_decode_attn_bf16"))
+                steps.append((lib.hk_decode_attn_bf16, [q, kc, vc, P(ws["kbias"]) if masked else None, att, B, H, hd, 0, rows, rows,
+                                                        ksplit, part], _ATTN, "hk_decode_attn_bf16"))
             gemv(att, o + "o", x, D, D, residual=x, out_f32=True)
             normed_gemv(w[o + "n2"], o + "gu", act, 2 * I, act="swiglu")
             gemv(act, o + "down", x, D, I, residual=x, out_f32=True)

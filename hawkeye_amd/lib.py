@@ -110,10 +110,10 @@ SYMBOLS = {
                                         C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
                                         C.c_float, C.c_void_p]),
     "hk_decode_attn_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
-                                      C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
+                                      C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "hk_decode_attn_rope_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
-                                           C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
+                                           C.c_int64, C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_void_p]),
     "hk_argmax_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
     "hk_silu_mul_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "hk_rmsnorm_add_parts": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,

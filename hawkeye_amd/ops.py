@@ -438,8 +438,14 @@ def decode_rope_append(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, 
     return q
 
 
+def _split_ws(B, H, head_dim, key_splits, device):
+    if key_splits <= 1:
+        return None
+    return torch.empty((B * H * min(key_splits, 16) * (head_dim + 2),), dtype=torch.float32, device=device)
+
+
 def decode_attn(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, n_keys: int, H: int, head_dim: int,
-                key_bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+                key_bias: Optional[torch.Tensor] = None, key_splits: int = 1) -> torch.Tensor:
     """One query row per (sequence, head) over cache rows [0, n_keys): bf16 [B, H*hd]."""
     _need(q, torch.bfloat16, "q")
     _need(k_cache, torch.bfloat16, "k_cache")
@@ -450,15 +456,16 @@ def decode_attn(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, n
         if key_bias.dim() != 2 or key_bias.shape[0] != B or key_bias.stride(1) != 1:
             raise RuntimeError("decode_attn: key_bias must be fp32 [B, >= n_keys]")
     out = torch.empty_like(q)
+    ws = _split_ws(B, H, head_dim, key_splits, q.device)
     L.check(L.load().hk_decode_attn_bf16(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), _ptr(key_bias), out.data_ptr(), B, H,
                                          head_dim, n_keys, k_cache.shape[1], 0 if key_bias is None else key_bias.stride(0),
-                                         _stream()), "hk_decode_attn_bf16")
+                                         key_splits, _ptr(ws), _stream()), "hk_decode_attn_bf16")
     return out
 
 
 def decode_attn_rope(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, pos0: torch.Tensor, pos_add: int,
                      k_cache: torch.Tensor, v_cache: torch.Tensor, slot: int, H: int, head_dim: int, q_scale: float,
-                     key_bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     key_bias: Optional[torch.Tensor] = None, key_splits: int = 1) -> torch.Tensor:
     """decode_rope_append + decode_attn over cache rows [0, slot] in one launch: bf16 [B, H*hd]."""
     _need(qkv, torch.bfloat16, "qkv")
     _need(pos0, torch.int32, "pos0")
@@ -473,10 +480,11 @@ def decode_attn_rope(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, po
     if key_bias is not None:
         _need(key_bias, torch.float32, "key_bias")
     out = torch.empty((B, D), dtype=torch.bfloat16, device=qkv.device)
+    ws = _split_ws(B, H, head_dim, key_splits, qkv.device)
     L.check(L.load().hk_decode_attn_rope_bf16(qkv.data_ptr(), cos.data_ptr(), sin.data_ptr(), pos0.data_ptr(), pos_add,
                                               k_cache.data_ptr(), v_cache.data_ptr(), _ptr(key_bias), out.data_ptr(), B, H, head_dim,
                                               slot, k_cache.shape[1], 0 if key_bias is None else key_bias.stride(0), cos.shape[0],
-                                              q_scale, _stream()), "hk_decode_attn_rope_bf16")
+                                              q_scale, key_splits, _ptr(ws), _stream()), "hk_decode_attn_rope_bf16")
     return out
 
 

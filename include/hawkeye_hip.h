@@ -253,7 +253,10 @@ int hk_decode_rope_append(const void* qkv, const float* cos_table, const float* 
  * natural-log domain (0 / -10000 from hk_qformer_key_bias for left-padded batches) or NULL; out bf16 [B, H*head_dim]. */
 int hk_decode_attn_bf16(const void* q, const void* k_cache, const void* v_cache, const float* key_bias, void* out,
                         int32_t B, int32_t H, int32_t head_dim, int32_t n_keys, int64_t cache_rows, int64_t bias_stride,
-                        void* stream);
+                        int32_t key_splits, float* split_ws, void* stream);
+/* key_splits > 1 with split_ws != NULL (fp32, B * H * min(key_splits, 16) * (head_dim + 2) elements, caller-owned): the keys of a
+ * long cache are divided over that many workgroups per (sequence, head) and merged by a second launch -- B * H workgroups are all
+ * the parallelism a decode step has otherwise.  Same result up to the order of the fp32 sums. */
 
 /* hk_decode_rope_append + hk_decode_attn_bf16 in one launch (the workgroup of a (sequence, head) is the only reader of that
  * head's new cache row, so it writes the row itself): qkv as hk_decode_rope_append takes it, n_keys = slot + 1.  Same
@@ -261,7 +264,7 @@ int hk_decode_attn_bf16(const void* q, const void* k_cache, const void* v_cache,
 int hk_decode_attn_rope_bf16(const void* qkv, const float* cos_table, const float* sin_table, const int32_t* pos0,
                              int32_t pos_add, void* k_cache, void* v_cache, const float* key_bias, void* out, int32_t B,
                              int32_t H, int32_t head_dim, int32_t slot, int64_t cache_rows, int64_t bias_stride,
-                             int32_t table_rows, float q_scale, void* stream);
+                             int32_t table_rows, float q_scale, int32_t key_splits, float* split_ws, void* stream);
 
 /* Greedy next token (do_sample=False, num_beams=1): out[r] = index of the largest of logits[r, 0:V] (row stride ld),
  * the lowest index among equals. */

@@ -157,6 +157,9 @@ def test_decode_attention_matches_fp32_softmax(B, H, hd, n, rows, masked):
         sc = sc + bias[:, None, None, :n]
     ref = (torch.softmax(sc, -1) @ v).permute(0, 2, 1, 3).reshape(B, D)
     assert _rel(got, ref) < 6e-3
+    # keys divided over several workgroups per (sequence, head) + merge launch
+    for ks in (2, 5, 16):
+        assert _rel(ops.decode_attn(q, kc, vc, n, H, hd, bias, key_splits=ks), ref) < 6e-3
 
 
 @pytest.mark.parametrize("B,H,hd,slot,rows,masked", [(1, 32, 128, 352, 448, False), (3, 2, 128, 96, 128, True), (2, 12, 64, 0, 8, False),
@@ -181,6 +184,10 @@ def test_fused_rope_append_attention_equals_the_two_launches(B, H, hd, slot, row
     one = ops.decode_attn_rope(qkv, cos, sin, pos0, 2, kc2, vc2, slot, H, hd, qs, bias)
     assert torch.equal(kc, kc2) and torch.equal(vc, vc2)
     assert _rel(one, two) < 1e-5 if not torch.equal(one, two) else True
+    kc3, vc3 = kc2.clone(), vc2.clone()
+    kc3[:, slot], vc3[:, slot] = 0, 0
+    split = ops.decode_attn_rope(qkv, cos, sin, pos0, 2, kc3, vc3, slot, H, hd, qs, bias, key_splits=3)
+    assert torch.equal(kc, kc3) and torch.equal(vc, vc3) and _rel(split, two) < 6e-3
 
 
 def test_argmax_lowest_index_among_equals():
