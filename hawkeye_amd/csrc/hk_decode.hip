@@ -60,7 +60,10 @@ __global__ __launch_bounds__(KS * 64) void hk_gemv_kernel(const GemvParams p) {
     const __bf16* xb = reinterpret_cast<const __bf16*>(p.x) + (int64_t)(mvalid ? i : 0) * p.ldx + koff;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-    constexpr int U = 4;   // K-blocks per group
+#ifndef HK_GEMV_U
+#define HK_GEMV_U 4
+#endif
+    constexpr int U = HK_GEMV_U;   // K-blocks per group
     bf16x8 wc[U][2];
     auto load_w = [&](bf16x8 (&w)[U][2], const __bf16* src) __attribute__((always_inline)) {
 #pragma unroll
