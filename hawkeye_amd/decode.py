@@ -180,6 +180,7 @@ class LlamaGenerator:
                  inputs_embeds: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
                  max_new_tokens: int = 20, stop_sequences: Optional[Sequence[Sequence[int]]] = None,
                  eos_token_id: Optional[int] = None, pad_token_id: int = 0, forced_tokens: Optional[torch.Tensor] = None,
+                 next_token_fn=None,
                  return_logits: bool = False, sync_every: int = 1):
         """Prompt arguments as LlamaPrefill.prefill (a mask, if given, must be all ones or LEFT-padded).  Greedy decoding:
         token 0 is the arg-max of the prefill's last-position logits, token t + 1 of decode step t's.
@@ -189,6 +190,10 @@ class LlamaGenerator:
         eos_token_id: a row that emits it is finished and gets pad_token_id from then on; generation ends when every row
         is finished (generate's unfinished_sequences bookkeeping).
         forced_tokens int64 [B, >= max_new_tokens]: feed these instead of the arg-max (teacher forcing: parity tests).
+        next_token_fn(logits fp32 [B, V], tokens_so_far int64 [B, t]) -> int64 [B] on the device: replaces the arg-max, e.g.
+        the reference's do_sample=True path (answer()'s default, tasks/test.py:111-112: temperature, top_p, repetition
+        penalty as transformers' LogitsProcessors + torch.multinomial), which stays PyTorch code of the caller's; the
+        forward of every step is still the HIP path.
         sync_every: the host looks at the new tokens every this many steps (1 = the reference's per-token check; larger
         values decode up to sync_every - 1 tokens past a stop and cut them off -- same output, fewer host round trips).
         Returns {"tokens": int64 [B, T] (T <= max_new_tokens), "logits": fp32 [T, B, V] if return_logits}."""
@@ -242,6 +247,11 @@ class LlamaGenerator:
             for t in range(max_new_tokens):
                 if forced_tokens is not None:
                     ws["tok"].copy_(forced_tokens[:, t])
+                elif next_token_fn is not None:
+                    nxt = next_token_fn(out["logits"] if t == 0 else ws["logits"], toks[:, :t])
+                    if nxt.dtype != torch.int64 or tuple(nxt.shape) != (B,) or not nxt.is_cuda:
+                        raise RuntimeError(f"generate: next_token_fn must return int64 [{B}] on the device")
+                    ws["tok"].copy_(nxt)
                 toks[:, t].copy_(ws["tok"])
                 n_out = t + 1
                 if (stops or eos_token_id is not None) and (n_out - checked >= sync_every or n_out == max_new_tokens):

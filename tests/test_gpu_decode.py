@@ -358,3 +358,31 @@ def test_generator_pool_survives_changing_shapes():
         m = torch.ones((1, 8), dtype=torch.int64, device=DEV)
         m[0, -1] = 0
         shared.generate(src=torch.zeros((1, 8), dtype=torch.int64, device=DEV), attention_mask=m, max_new_tokens=2)
+
+
+def test_next_token_hook_replaces_the_argmax():
+    """do_sample=True callers plug their own sampler: with torch.argmax as the hook the output is the greedy one; the hook
+    sees the logits of every step and the tokens generated so far."""
+    from hawkeye_amd.llm import LlamaPrefill
+    from hawkeye_amd.decode import LlamaGenerator
+    cfg = SMALL_LLM
+    pre = LlamaPrefill(cfg, DEV).load_state_dict(W.make_llm_state_dict(cfg, 13))
+    gen = LlamaGenerator(pre)
+    src, _ = W.make_prompt(cfg, 2, 40, 8, 13, ragged=False)
+    video = W._normal("video_tokens", 13, (16, cfg.hidden_size), 0.05).to(DEV)
+    src = src.to(DEV)
+    greedy = gen.generate(src=src, video=video, max_new_tokens=6, return_logits=True)
+    seen = []
+
+    def hook(logits, so_far):
+        seen.append((logits.clone(), so_far.clone()))
+        return torch.argmax(logits, -1)
+
+    hooked = gen.generate(src=src, video=video, max_new_tokens=6, next_token_fn=hook)
+    assert torch.equal(hooked["tokens"], greedy["tokens"]) and len(seen) == 6
+    for t, (lg, so_far) in enumerate(seen):
+        assert torch.equal(lg, greedy["logits"][t]) and torch.equal(so_far, greedy["tokens"][:, :t])
+    fixed = gen.generate(src=src, video=video, max_new_tokens=4, next_token_fn=lambda lg, s: torch.full((2,), 7, dtype=torch.int64, device=DEV))
+    assert bool((fixed["tokens"] == 7).all())
+    with pytest.raises(RuntimeError, match="next_token_fn"):
+        gen.generate(src=src, video=video, max_new_tokens=2, next_token_fn=lambda lg, s: torch.zeros(2, device=DEV))
