@@ -113,6 +113,8 @@ class HipEncoderEngine:
         self.w: Dict[str, torch.Tensor] = {}
         self.plans: "OrderedDict[Tuple[int, int, int], _Plan]" = OrderedDict()
         self.pool = _Pool(self.device)
+        self.w_tiled = os.environ.get("HK_VIT_TILED", "0") == "1"
+        self._w64: Dict[Tuple, torch.Tensor] = {}
         self.calls = 0          # every call that writes the pooled workspace counts (the training path's in-flight guard)
         self.n_cross = len([i for i in range(cfg.qf_layers) if i % cfg.cross_attention_freq == 0])
         self._tag = ""          # label of the plan steps being appended (profile() groups by it)
@@ -230,6 +232,14 @@ class HipEncoderEngine:
 
     # ------------------------------------------------------------------ plan
     def _gemm(self, plan, A, W, Cout, M, N, K, **kw):
+        # HK_VIT_TILED=1 (experiment, default off): stream a 64 x 64-block copy of the weight (hk_gemm_desc.w_tiled)
+        if self.w_tiled and "ldw" not in kw and W.dim() == 2 and W.is_contiguous() and N % 64 == 0 and K % 64 == 0 \
+                and tuple(W.shape) == (N, K):
+            key = (W.data_ptr(), N, K)
+            t = self._w64.get(key)
+            if t is None:
+                t = self._w64[key] = ops.tile_gemm_weight(W)
+            W, kw = t, dict(kw, w_tiled=True)
         d = ops.gemm_desc(A, W.data_ptr(), Cout, M, N, K, **kw)
         plan.keep.append(d)
         plan.steps.append((self.lib.hk_gemm_bf16, (C.byref(d),), "hk_gemm_bf16", self._tag))
