@@ -553,3 +553,25 @@ def test_outlier_statistics_golden(golden_dir, monkeypatch, residual_dtype, epi_
     keep = np.nonzero(rows % S < 96)[0]
     cols = torch.from_numpy(g[f"digest.{stage}.cols"]).to(DEV)
     _check(f"{tag}.{stage}.query_rows", ws["hf"][torch.from_numpy(rows[keep]).to(DEV)][:, cols], g[f"digest.{stage}.slice"][keep])
+
+
+@pytest.mark.parametrize("B,T", [(1, 12), (9, 8)])
+def test_tiled_weight_copies_give_the_row_major_bits(monkeypatch, B, T):
+    """HK_VIT_TILED=1: every GEMM of the call streams a 64 x 64-block copy of its weight (hk_gemm_desc.w_tiled) -- folded
+    LayerNorm, in-place residual with row statistics, split-K, tail launches, the Q-Former's small layers: same bits."""
+    cfg, seed = FULL, 29
+    sd = W.make_state_dict(cfg, seed)
+    image = W.make_clip(B, T, cfg.img_size, seed).to(DEV)
+    ids, mask = W.make_instruction_ids(B, 9, cfg.qf_vocab, seed, ragged=True)
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("HK_VIT_TILED", flag)
+        m = HawkEyeEncoder(cfg, out_dtype=torch.float32)
+        m.load_state_dict(sd, strict=True)
+        m = m.to(DEV).eval()
+        m.device_pos_embed = True
+        outs.append(m.encode_img(image, (ids, mask))[0].clone())
+        assert m.sync_engine().w_tiled == (flag == "1")
+        if flag == "1":
+            assert len(m.sync_engine()._w64) > 100
+    assert torch.equal(outs[0], outs[1])
