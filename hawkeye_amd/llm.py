@@ -72,6 +72,8 @@ class LlamaPrefill:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("LlamaPrefill runs on an MI355X only (device must be cuda:N)")
+        if self.device.index is None:       # "cuda" -> the current device, so that tensors on cuda:N compare equal to it
+            self.device = torch.device("cuda", torch.cuda.current_device())
         if cfg.head_dim not in (64, 128):
             raise RuntimeError(f"head size {cfg.head_dim} not supported by the HIP attention kernels (64 or 128)")
         if cfg.hidden_size % 256 or cfg.intermediate_size % 64:

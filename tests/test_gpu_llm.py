@@ -282,3 +282,12 @@ def test_prefill_workspace_is_pooled_across_prompt_lengths():
         src, want = outs[S]
         assert torch.equal(fresh.prefill(src=src)["logits"], want), S
         assert torch.equal(m.prefill(src=src)["logits"], want), S      # revisited after the others used the same buffers
+
+
+def test_bare_cuda_device_string_is_the_current_device():
+    """INTEGRATION.md builds LlamaPrefill(device="cuda"): inputs on cuda:0 must be accepted."""
+    pre = LlamaPrefill(SMALL_LLM, "cuda").load_state_dict(W.make_llm_state_dict(SMALL_LLM, 2))
+    src, _ = W.make_prompt(SMALL_LLM, 1, 24, 8, 2, ragged=False)
+    video = W._normal("video_tokens", 2, (8, SMALL_LLM.hidden_size), 0.05)
+    out = pre.prefill(src=src.to("cuda:0"), video=video.to("cuda:0"))
+    assert torch.isfinite(out["logits"]).all()
