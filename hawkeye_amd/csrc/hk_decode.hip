@@ -10,6 +10,16 @@
 
 namespace {
 
+// weight loads: streamed once per token, marked non-temporal (-DHK_GEMV_NT=0: plain loads, A/B aid)
+#ifndef HK_GEMV_NT
+#define HK_GEMV_NT 1
+#endif
+#if HK_GEMV_NT
+#define HK_WLOAD(p) __builtin_nontemporal_load(p)
+#else
+#define HK_WLOAD(p) (*(p))
+#endif
+
 struct GemvParams {
     const void* x;          // bf16 [M][K], or fp32 when norm_w is set
     const __bf16* W;
@@ -68,8 +78,8 @@ __global__ __launch_bounds__(KS * 64) void hk_gemv_kernel(const GemvParams p) {
     auto load_w = [&](bf16x8 (&w)[U][2], const __bf16* src) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            w[u][0] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(src + u * wstep));
-            w[u][1] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(src + u * wstep + whalf));
+            w[u][0] = HK_WLOAD(reinterpret_cast<const bf16x8*>(src + u * wstep));
+            w[u][1] = HK_WLOAD(reinterpret_cast<const bf16x8*>(src + u * wstep + whalf));
         }
     };
     int b = b0;
@@ -190,8 +200,8 @@ __global__ __launch_bounds__(KS * 64) void hk_gemv_kernel(const GemvParams p) {
         xl += U * 64;
     }
     for (; b < b1; ++b) {
-        const bf16x8 w0 = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp));
-        const bf16x8 w1 = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + whalf));
+        const bf16x8 w0 = HK_WLOAD(reinterpret_cast<const bf16x8*>(wp));
+        const bf16x8 w1 = HK_WLOAD(reinterpret_cast<const bf16x8*>(wp + whalf));
         bf16x8 x0, x1;
         load_x(x0, x1, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x0, acc, 0, 0, 0);
