@@ -48,7 +48,10 @@ __device__ __forceinline__ float silu_mul_d(const float g, const float u) {   //
 // NORM: x is the fp32 residual stream and the operand is RMSNorm(x) * norm_w (modeling_llama.py:57-75) rounded to bf16 --
 // hk_rmsnorm's arithmetic, without its launch and its [M, K] round trip: every workgroup sums the squares of the M <= 4
 // rows itself (16 KB each from L2, while its first weight loads are in flight) and normalises the fragments as it loads them.
-template <int KS, int MODE>   // MODE 0: x fragments from global memory; 1: bf16 x staged in LDS; 2: RMSNorm(x) staged in LDS
+// KEEP (NORM only): rows whose fp32 chunks stay in registers between the statistics pass and the normalising pass (1 for M = 1,
+// 4 for M = 2..4 when a thread holds <= 4 chunks per row; 0 = the second pass reads x again: 176 MB of L2 reads per gate|up launch
+// at M = 4, as much as the weights themselves).
+template <int KS, int MODE, int KEEP = 0>   // MODE 0: x fragments from global memory; 1: bf16 x staged in LDS; 2: RMSNorm(x) staged in LDS
 __global__ __launch_bounds__(KS * 64) void hk_gemv_kernel(const GemvParams p) {
     constexpr bool NORM = MODE == 2, XLDS = MODE != 0;
     __shared__ f32x4 red[KS][64];
@@ -92,6 +95,7 @@ __global__ __launch_bounds__(KS * 64) void hk_gemv_kernel(const GemvParams p) {
         __shared__ float ssq[KS][4];
         constexpr int NV = 16 / KS > 0 ? 16 / KS : 1;   // K <= NV * KS * 256 = 4096 elements, checked by the host
         float ss[4] = {0.f, 0.f, 0.f, 0.f};
+        f32x4 kept[KEEP > 0 ? KEEP : 1][NV];
 #pragma unroll
         for (int m = 0; m < 4; ++m)
             if (m < p.M) {
@@ -101,6 +105,7 @@ __global__ __launch_bounds__(KS * 64) void hk_gemv_kernel(const GemvParams p) {
                     const int k = (j * KS * 64 + tid) * 4;
                     v[j] = k < p.K ? *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.x) + (int64_t)m * p.ldx + k)
                                    : f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (m < KEEP) kept[m][j] = v[j];
                 }
 #pragma unroll
                 for (int j = 0; j < NV; ++j) ss[m] += v[j][0] * v[j][0] + v[j][1] * v[j][1] + v[j][2] * v[j][2] + v[j][3] * v[j][3];
@@ -117,26 +122,31 @@ __global__ __launch_bounds__(KS * 64) void hk_gemv_kernel(const GemvParams p) {
         }
         __syncthreads();
         __bf16* xs = reinterpret_cast<__bf16*>(xs_raw);
+        float rinv[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-            if (m < p.M) {
-                float tot = 0.f;
+        for (int m = 0; m < 4; ++m) {
+            float tot = 0.f;
 #pragma unroll
-                for (int w = 0; w < KS; ++w) tot += ssq[w][m];
-                const float rinv = rsqrtf(tot / (float)p.K + p.eps);
+            for (int w = 0; w < KS; ++w) tot += ssq[w][m];
+            rinv[m] = rsqrtf(tot / (float)p.K + p.eps);
+        }
 #pragma unroll
-                for (int j = 0; j < NV; ++j) {
-                    const int k = (j * KS * 64 + tid) * 4;
-                    if (k < p.K) {
-                        const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.x) + (int64_t)m * p.ldx + k);
-                        const f32x4 g = *reinterpret_cast<const f32x4*>(p.norm_w + k);
+        for (int j = 0; j < NV; ++j) {
+            const int k = (j * KS * 64 + tid) * 4;
+            if (k < p.K) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(p.norm_w + k);      // once per chunk, not per row
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    if (m < p.M) {
+                        const f32x4 v = m < KEEP ? kept[m][j]
+                                                 : *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.x) + (int64_t)m * p.ldx + k);
                         u32x2 o;
-                        o[0] = pack_bf16x2(g[0] * (v[0] * rinv), g[1] * (v[1] * rinv));
-                        o[1] = pack_bf16x2(g[2] * (v[2] * rinv), g[3] * (v[3] * rinv));
+                        o[0] = pack_bf16x2(g[0] * (v[0] * rinv[m]), g[1] * (v[1] * rinv[m]));
+                        o[1] = pack_bf16x2(g[2] * (v[2] * rinv[m]), g[3] * (v[3] * rinv[m]));
                         *reinterpret_cast<u32x2*>(xs + m * xld + k) = o;
                     }
-                }
             }
+        }
         __syncthreads();
     } else if constexpr (XLDS) {
         // the operand rows -> LDS (their loads are older than the weight loads and return first): the main loop's only
@@ -530,6 +540,19 @@ __global__ __launch_bounds__(1024) void hk_argmax_kernel(const float* __restrict
 
 }  // namespace
 
+namespace {
+template <int KS, int MODE, int KEEP>
+int launch_gemv(const GemvParams& p, dim3 grid, size_t xlds, hipStream_t s) {
+    static std::atomic<unsigned long long> done{0};
+    if (xlds > 40 * 1024) {
+        const hipError_t e = hk_lds_attr_once(done, reinterpret_cast<const void*>(&hk_gemv_kernel<KS, MODE, KEEP>), 128 * 1024);
+        HK_REQUIRE(e == hipSuccess, "hk_gemv_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL((hk_gemv_kernel<KS, MODE, KEEP>), grid, dim3(KS * 64), xlds, s, p);
+    return HK_OK;
+}
+}  // namespace
+
 extern "C" int hk_gemv_bf16(const hk_gemv_desc* d, void* stream) {
     HK_REQUIRE(d && d->x && d->W && d->out, "hk_gemv_bf16: null pointer");
     HK_REQUIRE(d->M >= 1 && d->M <= 16, "hk_gemv_bf16: M=%d rows (1..16: the decode step; larger batches go through hk_gemm_bf16)", d->M);
@@ -572,25 +595,33 @@ extern "C" int hk_gemv_bf16(const hk_gemv_desc* d, void* stream) {
     if (force == 1 || force == 2 || force == 4 || force == 8 || force == 16) ks = force;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)nb);
-    // operand rows staged in LDS when they fit beside a few workgroups per CU (always for the fused norm: K <= 4096, M <= 4)
+    // operand rows staged in LDS when they fit beside a few workgroups per CU (always for the fused norm: K <= 4096, M <= 4);
+    // a launch of at most one workgroup per CU (o_proj / down_proj: 256 row blocks) may take most of the CU's LDS for them
     const size_t xbytes = (size_t)p.M * (p.K + 64) * 2;
     static const int xl_env = getenv("HK_GEMV_XLDS") ? atoi(getenv("HK_GEMV_XLDS")) : 1;   // A/B aid: 0 = fragments from global memory
-    const int mode = p.norm_w ? 2 : (xl_env != 0 && xbytes <= 40 * 1024) ? 1 : 0;      // + up to 16 KB of static LDS stays under 64 KB
+    const size_t xmax = nb <= 256 ? 128 * 1024 : 40 * 1024;      // + up to 16 KB of static LDS
+    const int mode = p.norm_w ? 2 : (xl_env != 0 && xbytes <= xmax) ? 1 : 0;
     const size_t xlds = mode ? xbytes : 0;
-#define HK_GEMV(KS_)                                                                                        \
-    case KS_:                                                                                               \
-        if (mode == 2) hipLaunchKernelGGL((hk_gemv_kernel<KS_, 2>), grid, dim3(KS_ * 64), xlds, s, p);      \
-        else if (mode == 1) hipLaunchKernelGGL((hk_gemv_kernel<KS_, 1>), grid, dim3(KS_ * 64), xlds, s, p); \
-        else hipLaunchKernelGGL((hk_gemv_kernel<KS_, 0>), grid, dim3(KS_ * 64), 0, s, p);                   \
+    static const int keep_env = getenv("HK_GEMV_KEEP") ? atoi(getenv("HK_GEMV_KEEP")) : 1;   // A/B aid: 0 = the second pass re-reads x
+    const int keep = (mode == 2 && keep_env) ? (p.M == 1 ? 1 : (ks >= 4 ? 4 : 0)) : 0;
+    int rc = HK_OK;
+#define HK_GEMV(KS_)                                                                         \
+    case KS_:                                                                                \
+        if (mode == 2 && keep == 1) rc = launch_gemv<KS_, 2, 1>(p, grid, xlds, s);          \
+        else if (mode == 2 && keep == 4) rc = launch_gemv<KS_, 2, (KS_ >= 4 ? 4 : 0)>(p, grid, xlds, s); \
+        else if (mode == 2) rc = launch_gemv<KS_, 2, 0>(p, grid, xlds, s);                  \
+        else if (mode == 1) rc = launch_gemv<KS_, 1, 0>(p, grid, xlds, s);                  \
+        else rc = launch_gemv<KS_, 0, 0>(p, grid, 0, s);                                    \
         break;
     switch (ks) {
         HK_GEMV(1) HK_GEMV(2) HK_GEMV(4) HK_GEMV(8)
         default:
-            if (mode == 2) hipLaunchKernelGGL((hk_gemv_kernel<16, 2>), grid, dim3(1024), xlds, s, p);
-            else if (mode == 1) hipLaunchKernelGGL((hk_gemv_kernel<16, 1>), grid, dim3(1024), xlds, s, p);
-            else hipLaunchKernelGGL((hk_gemv_kernel<16, 0>), grid, dim3(1024), 0, s, p);
+            if (mode == 2) rc = launch_gemv<16, 2, 0>(p, grid, xlds, s);
+            else if (mode == 1) rc = launch_gemv<16, 1, 0>(p, grid, xlds, s);
+            else rc = launch_gemv<16, 0, 0>(p, grid, 0, s);
     }
 #undef HK_GEMV
+    if (rc != HK_OK) return rc;
     HK_CHECK_LAUNCH("hk_gemv_bf16");
     return HK_OK;
 }
